@@ -1,0 +1,297 @@
+/*
+ * rtx.h -- C ABI of the MI355X trace-loop library (librtx_hip.so).
+ *
+ * The reference renderer (noahwhygodwhy/Raytracer) has no FFI: its per-pixel
+ * trace loop is a set of C++ call sites inside one executable.  This header is
+ * the seam introduced between the reference's frame driver (main(),
+ * Raytracer/Raytracer.cpp:595-752) and everything below it.  Each entry point
+ * names the reference call site it replaces.
+ *
+ * All pointers are plain host pointers unless the name says `_device`.
+ * All arrays are tightly packed, little endian.  Vectors are xyz triples.
+ * Every function returns RTX_OK (0) or a negative rtx_status; the message for
+ * the calling thread's last failure is available from rtx_last_error().
+ * Nothing here exits the process or throws (the reference printf+exit(-1)s,
+ * e.g. Raytracer/SquareLight.cpp:80-90).
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_ABI_VERSION 1
+
+typedef enum rtx_status {
+    RTX_OK = 0,
+    RTX_ERR_INVALID = -1,   /* bad argument / malformed scene description   */
+    RTX_ERR_DEVICE = -2,    /* HIP runtime failure                           */
+    RTX_ERR_LIMIT = -3,     /* a documented size limit was exceeded          */
+    RTX_ERR_NO_GPU = -4     /* no usable gfx950 device                       */
+} rtx_status;
+
+/* ---- shape tags (reference: virtual Shape::rayHit, Raytracer/Shape.hpp:52-65) */
+enum { RTX_PRIM_TRIANGLE = 0, RTX_PRIM_SPHERE = 1, RTX_PRIM_BICONVEX = 2 };
+
+/* ---- per-channel material sampler (reference: std::function members,
+ *      Raytracer/Material.hpp:70-76; callables cannot cross a C ABI so the
+ *      host classes record which factory produced them) */
+enum {
+    RTX_SAMPLER_CONST = 0,          /* no callback: use the constant field            */
+    RTX_SAMPLER_RY_CHECKERS = 1,    /* ryCheckers10x10, Raytracer/Procedural.cpp:4-14 */
+    RTX_SAMPLER_DOUBLE_CHECKERS = 2,/* doubleCheckers10x10, Procedural.cpp:16-25      */
+    RTX_SAMPLER_TEXTURE_VEC3 = 3,   /* Texture::vec3Sample via getVec3Sampler (float) */
+    RTX_SAMPLER_TEXTURE_DOUBLE = 4  /* Texture::doubleSample, Texture.cpp:56-64       */
+};
+
+typedef struct rtx_sampler {
+    uint32_t kind;      /* RTX_SAMPLER_*                       */
+    uint32_t texture;   /* index into rtx_scene_desc.textures  */
+} rtx_sampler;
+
+/* reference: class Material, Raytracer/Material.hpp:25-85 */
+typedef struct rtx_material {
+    double color[3];
+    double ns;
+    double ni;
+    double transparency;
+    double metalness;
+    double smoothness;
+    double emission[3];
+    rtx_sampler color_fn;
+    rtx_sampler ns_fn;
+    rtx_sampler ni_fn;
+    rtx_sampler transparency_fn;
+    rtx_sampler metalness_fn;
+    rtx_sampler smoothness_fn;
+} rtx_material;
+
+/* reference: class Texture, Raytracer/Texture.hpp:17-33 (RGB8, 3 channels forced) */
+typedef struct rtx_texture {
+    uint32_t width;
+    uint32_t height;
+    uint64_t offset;    /* byte offset of texel (0,0) in rtx_scene_desc.texels */
+} rtx_texture;
+
+enum { RTX_LIGHT_POINT = 0, RTX_LIGHT_DIRECTIONAL = 1, RTX_LIGHT_SQUARE = 2 };
+
+/* reference: Light / PointLight / DirectionalLight / SquareLight,
+ * Raytracer/Light.hpp:13-26, PointLight.cpp, DirectionalLight.cpp, SquareLight.cpp */
+typedef struct rtx_light {
+    uint32_t kind;          /* RTX_LIGHT_*                                          */
+    uint32_t multisample;   /* Light::multisample (true only for SquareLight)       */
+    double color[3];
+    double position[3];     /* point / square                                       */
+    double direction[3];    /* directional: reverseDirection (unit, pointing to the
+                               light); square: unit normal                          */
+    double right[3];        /* square frame, SquareLight.cpp:16-23                  */
+    double up[3];
+    double bottom_left[3];  /* SquareLight.cpp:34                                   */
+    double width;
+    double height;
+} rtx_light;
+
+/*
+ * One frame's flattened scene = reference FrameInfo (Raytracer/Raytracer.hpp:60-67,
+ * plus `lights` from Raytracer-Noah-Desktop.cpp:104-111) after redoAABBs +
+ * buildKDTree (Raytracer.cpp:634-636) with Animatable::getModel(t) evaluated.
+ *
+ * KD child encoding: c >= 0 is branch index c; c < 0 is leaf index ~c.
+ * Leaves are numbered in the walk order of printKDTree (KDTree.cpp:137-155:
+ * lesser subtree first), so a ray's leaf-visit sequence is strictly increasing.
+ * Primitive ids 0..n_shapes-1 are positions in FrameInfo::shapes; ids
+ * n_shapes..n_prims-1 are the private inner spheres of Biconvex lenses
+ * (Biconvex.cpp:43-44), which the reference reports as HitResult::shape.
+ */
+typedef struct rtx_scene_desc {
+    uint32_t abi_version;       /* RTX_ABI_VERSION */
+
+    /* KD tree (KDBranch / KDLeaf, Raytracer/KDTree.hpp:31-55) */
+    int32_t  kd_root;
+    uint32_t n_branches;
+    uint32_t n_leaves;
+    uint32_t n_leaf_refs;
+    const double*   branch_min;     /* [n_branches*3]  KDBranch::area.min        */
+    const double*   branch_max;     /* [n_branches*3]  KDBranch::area.max        */
+    const double*   branch_value;   /* [n_branches]                              */
+    const int32_t*  branch_axis;    /* [n_branches]    0,1,2                     */
+    const int32_t*  branch_lesser;  /* [n_branches]    child encoding            */
+    const int32_t*  branch_greater; /* [n_branches]                              */
+    const uint32_t* leaf_first;     /* [n_leaves]      into leaf_refs            */
+    const uint32_t* leaf_count;     /* [n_leaves]                                */
+    const uint32_t* leaf_refs;      /* [n_leaf_refs]   primitive ids             */
+
+    /* primitives */
+    uint32_t n_shapes;              /* entries of FrameInfo::shapes              */
+    uint32_t n_prims;               /* n_shapes + hidden lens spheres            */
+    const uint8_t*  prim_type;      /* [n_prims] RTX_PRIM_*                      */
+    const uint32_t* prim_index;     /* [n_prims] index into the per-type arrays  */
+    const uint32_t* prim_material;  /* [n_prims] (ignored for BICONVEX)          */
+    const double*   prim_aabb_min;  /* [n_prims*3] Shape::boundingBox            */
+    const double*   prim_aabb_max;  /* [n_prims*3]                               */
+
+    uint32_t n_triangles;
+    const double* tri_position;     /* [n_triangles*9]  a,b,c                    */
+    const double* tri_normal;       /* [n_triangles*9]  per-vertex normals       */
+    const double* tri_uv;           /* [n_triangles*6]  per-vertex texCoords     */
+
+    uint32_t n_spheres;
+    const double* sphere_center;    /* [n_spheres*3] transformPos(origin, model) */
+    const double* sphere_radius;    /* [n_spheres]                               */
+    const double* sphere_r2;        /* [n_spheres]                               */
+    const double* sphere_normal_matrix; /* [n_spheres*16] inverse(transpose(model)),
+                                       column major (glm layout)                 */
+
+    uint32_t n_lenses;
+    const uint32_t* lens_spheres;   /* [n_lenses*2] primitive ids of s1, s2      */
+
+    uint32_t n_materials;
+    const rtx_material* materials;
+
+    uint32_t n_textures;
+    const rtx_texture* textures;
+    uint64_t n_texel_bytes;
+    const uint8_t* texels;
+
+    uint32_t n_lights;
+    const rtx_light* lights;
+} rtx_scene_desc;
+
+/* camera basis computed by the frame driver, Raytracer/Raytracer.cpp:642-660 */
+typedef struct rtx_camera {
+    double eye[3];
+    double right[3];
+    double up[3];
+    double forward[3];
+    double focal;
+} rtx_camera;
+
+enum { RTX_INTEGRATOR_PATH = 0,     /* pathTrace, Raytracer/Raytracer.cpp:217-355       */
+       RTX_INTEGRATOR_WHITTED = 1   /* rayTrace, Raytracer-Noah-Desktop.cpp:452-564     */ };
+
+enum {
+    RTX_FLAG_LINEAR_SCAN     = 1u << 0, /* !KDTRACE: rayHitListOfShapes over all shapes
+                                           (Raytracer.cpp:114-118)                         */
+    RTX_FLAG_BASIC           = 1u << 1, /* BASIC_BITCH: colour of the first hit
+                                           (Raytracer.cpp:228-230)                         */
+    RTX_FLAG_NO_LIGHTING     = 1u << 2, /* Whitted without LIGHTING
+                                           (Raytracer-Noah-Desktop.cpp:555)                */
+    RTX_FLAG_WHITTED_REFLECT = 1u << 3, /* extension, not in the reference: a mirror ray
+                                           as in pathTrace case 2 (Raytracer.cpp:284-285)
+                                           blended by smoothness                           */
+    RTX_FLAG_COUNTERS        = 1u << 4, /* fill the traversal work counters of rtx_stats   */
+    RTX_FLAG_PER_LANE        = 1u << 5, /* force the one-ray-per-lane traversal kernel     */
+    RTX_FLAG_PACKET          = 1u << 6  /* force the wave-packet traversal kernel          */
+};
+
+/* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;
+ * Raytracer-Noah-Desktop.cpp:61-80,101) as run-time fields. */
+typedef struct rtx_render_desc {
+    uint32_t integrator;            /* RTX_INTEGRATOR_*                                 */
+    uint32_t flags;                 /* RTX_FLAG_*                                       */
+    uint32_t width;                 /* frameX                                           */
+    uint32_t height;                /* frameY                                           */
+    uint32_t tile_x0, tile_y0;      /* sub-rectangle rendered by this call              */
+    uint32_t tile_w, tile_h;        /*   (0,0,width,height for the full frame)          */
+    uint32_t pixel_multisample_n;   /* PIXEL_MULTISAMPLE_N (n*n sub-samples)            */
+    uint32_t light_multisample_n;   /* LIGHT_MULTISAMPLES_N                             */
+    uint32_t max_depth;             /* MAX_PATH (path) / MAXBOUNCES (Whitted)           */
+    uint32_t first_pass;            /* index of the first Monte-Carlo pass of this call */
+    uint32_t passes;                /* number of passes accumulated by this call        */
+    uint32_t frame;                 /* RNG key component                                */
+    uint64_t seed;                  /* RNG key component (reference: srand(0u))         */
+    double bias;
+    double clear_color[3];
+    double attenuation[3];          /* LIGHT_CONTSTANT, LIGHT_LINEAR, LIGHT_QUADRATIC   */
+    rtx_camera camera;
+} rtx_render_desc;
+
+typedef struct rtx_stats {
+    /* closest-hit queries (= shootRay calls) by kind; always filled */
+    uint64_t rays_primary;
+    uint64_t rays_secondary;
+    uint64_t rays_shadow;
+    /* per-ray work counters summed over all queries; filled with RTX_FLAG_COUNTERS */
+    uint64_t branch_visits;         /* KDBranch slab tests                       */
+    uint64_t leaf_visits;
+    uint64_t aabb_tests;            /* Shape::rayAABB calls                      */
+    uint64_t triangle_tests;        /* Triangle::rayHit calls                    */
+    uint64_t sphere_tests;          /* Sphere::rayHit calls (2 per lens)         */
+    uint64_t hits_accepted;         /* closer-hit replacements                   */
+    /* device time per stage in milliseconds (HIP events on the library stream) */
+    double ms_generate;
+    double ms_traverse;
+    double ms_shade;
+    double ms_shadow;
+    double ms_resolve;
+    double ms_total;
+    uint32_t traverse_launches;
+    uint32_t max_queue;
+} rtx_stats;
+
+typedef struct rtx_scene rtx_scene;
+
+/* Select the device and create library state.  device < 0 keeps the current one. */
+int rtx_init(int device);
+
+/* Number of visible HIP devices (0 when there is none). */
+int rtx_device_count(void);
+
+/* Upload one frame's flattened scene.  Replaces: FrameInfo handed to the
+ * per-pixel lambda (Raytracer.cpp:553-557,634-636).  The library copies
+ * everything; the caller keeps ownership of the host arrays. */
+int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out);
+
+/* Run later work for this scene on `hip_stream` (a hipStream_t; NULL = default). */
+int rtx_scene_set_stream(rtx_scene* scene, void* hip_stream);
+
+void rtx_scene_destroy(rtx_scene* scene);
+
+/*
+ * Batched shootRay (Raytracer.cpp:108-120): for each i builds
+ * Ray(origin_i, direction_i) (Ray.cpp:3-8, normalising the direction) and
+ * returns the closest hit.  Output arrays may be NULL except prim and depth.
+ *   prim[i]        primitive id or -1           depth[i]   HitResult::depth (+inf on miss)
+ *   position/normal [n*3], uv [n*2], bary [n*3] HitResult fields of the winner
+ *   leaf_count[i]  number of KDLeaf visits      leaf_hash[i]  FNV-1a-64 over the leaf ids
+ *   leaf_seq       [n*leaf_seq_cap] first leaf ids visited, rest untouched
+ *   counters       [n*6] branch, leaf, aabb, triangle, sphere, accepted per ray
+ * flags: RTX_FLAG_LINEAR_SCAN, RTX_FLAG_PER_LANE, RTX_FLAG_PACKET.
+ */
+int rtx_trace_closest(rtx_scene* scene, const double* origin, const double* direction, size_t n,
+                      uint32_t flags, int32_t* prim, double* depth, double* position,
+                      double* normal, double* uv, double* bary, uint32_t* leaf_count,
+                      uint64_t* leaf_hash, uint32_t* leaf_seq, uint32_t leaf_seq_cap,
+                      uint32_t* counters);
+
+/*
+ * The per-pixel lambda plus integrator (Raytracer.cpp:672-716 calling pathTrace,
+ * or rayTrace of Raytracer-Noah-Desktop.cpp:452-564), for `passes` passes of the
+ * Monte-Carlo loop (Raytracer.cpp:666).  `accum` is the tile's slice of the
+ * reference's drawBuffer: float RGB, tile_w*tile_h*3, row 0 = bottom row; each
+ * pass performs accum[p] += float(colorAcum / (n*n)) in pass order (FP32, as
+ * Raytracer.hpp:77-78).  The caller initialises it (clearBuffers, :53-58).
+ * rtx_render takes a host buffer; rtx_render_device takes device memory, runs
+ * asynchronously on the scene's stream when stats == NULL, and is what a caller
+ * with resident buffers (a multi-GPU gather) uses.
+ */
+int rtx_render(rtx_scene* scene, const rtx_render_desc* desc, float* accum, rtx_stats* stats);
+int rtx_render_device(rtx_scene* scene, const rtx_render_desc* desc, float* accum_device,
+                      rtx_stats* stats);
+
+/* The draw-index'th uniform of one sample's random stream, in [0,1]
+ * (replaces rand()/RAND_MAX, Raytracer.cpp:65-67).  Exposed so a host-side
+ * reference can be driven with identical samples. */
+double rtx_uniform(uint64_t seed, uint32_t frame, uint32_t pixel, uint32_t sample,
+                   uint32_t branch, uint32_t draw_index);
+
+const char* rtx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

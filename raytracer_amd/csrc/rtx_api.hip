@@ -1,0 +1,608 @@
+// rtx_api.hip -- the C ABI of include/rtx.h over the kernels of rtx_kernels.hpp.
+//
+// Host responsibilities: validate the flattened scene (a malformed tree would make
+// a kernel read out of bounds), lay it out in device memory, own the ray queues,
+// and drive the per-level loop of the wavefront pipeline.  There is no CPU
+// implementation of any stage here: without a working HIP device every entry
+// point fails with RTX_ERR_NO_GPU / RTX_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rtx_kernels.hpp"
+
+using namespace rtx;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(RTX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceBuffers {
+    std::vector<void*> ptrs;
+    ~DeviceBuffers() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T>
+    hipError_t upload(const T* host, size_t count, const T** out)
+    {
+        *out = nullptr;
+        if (count == 0) return hipSuccess;
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, count * sizeof(T));
+        if (e != hipSuccess) return e;
+        ptrs.push_back(p);
+        e = hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice);
+        *out = static_cast<const T*>(p);
+        return e;
+    }
+};
+
+// Growable device workspace for the ray queues.
+struct Workspace {
+    size_t capacity = 0;            // rays per queue
+    size_t shadow_capacity = 0;
+    char* base = nullptr;
+    char* shadow_base_mem = nullptr;
+    RayQueue q[2];
+    ShadowQueue sq;
+    uint32_t* shadow_index = nullptr;       // per ray: first shadow entry
+    double* sample = nullptr;               // 3 per slot
+    uint32_t* counts = nullptr;             // [0] next queue, [1] shadow queue, [2] generate
+    unsigned long long* work = nullptr;     // 6 counters
+    uint32_t* host_counts = nullptr;        // pinned
+    unsigned long long* host_work = nullptr;
+    ~Workspace()
+    {
+        if (base) (void)hipFree(base);
+        if (shadow_base_mem) (void)hipFree(shadow_base_mem);
+        if (counts) (void)hipFree(counts);
+        if (work) (void)hipFree(work);
+        if (host_counts) (void)hipHostFree(host_counts);
+        if (host_work) (void)hipHostFree(host_work);
+    }
+};
+
+template <class T>
+T* carve(char*& p, size_t count)
+{
+    T* r = reinterpret_cast<T*>(p);
+    p += ((count * sizeof(T) + 255) / 256) * 256;
+    return r;
+}
+
+size_t queue_bytes(size_t cap)
+{
+    auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
+    size_t per_queue = 10 * al(cap * 8) + 4 * al(cap * 4) + al(cap * 4) + al(cap * 8);
+    return 2 * per_queue + al(cap * 4) + al(cap * 3 * 8);
+}
+
+}  // namespace
+
+struct rtx_scene {
+    DScene d;
+    DeviceBuffers buffers;
+    Workspace ws;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    uint32_t kd_depth = 0;
+};
+
+namespace {
+
+int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap)
+{
+    Workspace& w = sc->ws;
+    if (!w.counts) {
+        HIP_TRY(hipMalloc(&w.counts, 4 * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&w.work, 6 * sizeof(unsigned long long)));
+        HIP_TRY(hipHostMalloc(&w.host_counts, 4 * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc(&w.host_work, 6 * sizeof(unsigned long long)));
+    }
+    if (cap > w.capacity) {
+        if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.capacity = 0; }
+        HIP_TRY(hipMalloc(&w.base, queue_bytes(cap)));
+        char* p = w.base;
+        for (int k = 0; k < 2; ++k) {
+            RayQueue& q = w.q[k];
+            q.ox = carve<double>(p, cap); q.oy = carve<double>(p, cap); q.oz = carve<double>(p, cap);
+            q.dx = carve<double>(p, cap); q.dy = carve<double>(p, cap); q.dz = carve<double>(p, cap);
+            q.wx = carve<double>(p, cap); q.wy = carve<double>(p, cap); q.wz = carve<double>(p, cap);
+            q.ior = carve<double>(p, cap);
+            q.slot = carve<uint32_t>(p, cap); q.layer = carve<uint32_t>(p, cap);
+            q.branch = carve<uint32_t>(p, cap); q.counter = carve<uint32_t>(p, cap);
+            q.hit_prim = carve<int32_t>(p, cap); q.hit_depth = carve<double>(p, cap);
+        }
+        w.shadow_index = carve<uint32_t>(p, cap);
+        w.sample = carve<double>(p, cap * 3);
+        w.capacity = cap;
+    }
+    if (shadow_cap > w.shadow_capacity) {
+        if (w.shadow_base_mem) { HIP_TRY(hipFree(w.shadow_base_mem)); w.shadow_base_mem = nullptr; w.shadow_capacity = 0; }
+        auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
+        HIP_TRY(hipMalloc(&w.shadow_base_mem, 7 * al(shadow_cap * 8)));
+        char* p = w.shadow_base_mem;
+        ShadowQueue& s = w.sq;
+        s.ox = carve<double>(p, shadow_cap); s.oy = carve<double>(p, shadow_cap); s.oz = carve<double>(p, shadow_cap);
+        s.dx = carve<double>(p, shadow_cap); s.dy = carve<double>(p, shadow_cap); s.dz = carve<double>(p, shadow_cap);
+        s.hit_depth = carve<double>(p, shadow_cap);
+        w.shadow_capacity = shadow_cap;
+    }
+    return RTX_OK;
+}
+
+// depth of the subtree under `node`, checking every index on the way; -1 = malformed
+int validate_tree(const rtx_scene_desc* s, int32_t node, int depth, std::vector<uint8_t>& seen_branch)
+{
+    if (depth > 64) return -1;
+    if (node < 0) {
+        uint32_t leaf = (uint32_t)~node;
+        if (leaf >= s->n_leaves) return -1;
+        uint64_t first = s->leaf_first[leaf], count = s->leaf_count[leaf];
+        if (first + count > s->n_leaf_refs) return -1;
+        return depth;
+    }
+    if ((uint32_t)node >= s->n_branches || seen_branch[node]) return -1;
+    seen_branch[node] = 1;
+    if (s->branch_axis[node] < 0 || s->branch_axis[node] > 2) return -1;
+    int a = validate_tree(s, s->branch_lesser[node], depth + 1, seen_branch);
+    if (a < 0) return -1;
+    int b = validate_tree(s, s->branch_greater[node], depth + 1, seen_branch);
+    if (b < 0) return -1;
+    return std::max(a, b);
+}
+
+int validate_scene(const rtx_scene_desc* s, uint32_t* kd_depth)
+{
+    if (!s) return fail(RTX_ERR_INVALID, "null scene description");
+    if (s->abi_version != RTX_ABI_VERSION) return fail(RTX_ERR_INVALID, "abi_version %u, library speaks %u", s->abi_version, RTX_ABI_VERSION);
+    if (s->n_shapes > s->n_prims) return fail(RTX_ERR_INVALID, "n_shapes > n_prims");
+    if (s->n_prims >= (1u << 30)) return fail(RTX_ERR_LIMIT, "too many primitives");
+    for (uint32_t i = 0; i < s->n_prims; ++i) {
+        uint32_t idx = s->prim_index[i];
+        switch (s->prim_type[i]) {
+        case RTX_PRIM_TRIANGLE: if (idx >= s->n_triangles) return fail(RTX_ERR_INVALID, "prim %u: triangle index out of range", i); break;
+        case RTX_PRIM_SPHERE: if (idx >= s->n_spheres) return fail(RTX_ERR_INVALID, "prim %u: sphere index out of range", i); break;
+        case RTX_PRIM_BICONVEX: if (idx >= s->n_lenses) return fail(RTX_ERR_INVALID, "prim %u: lens index out of range", i); break;
+        default: return fail(RTX_ERR_INVALID, "prim %u: unknown type %u", i, s->prim_type[i]);
+        }
+        if (s->prim_type[i] != RTX_PRIM_BICONVEX && s->prim_material[i] >= s->n_materials)
+            return fail(RTX_ERR_INVALID, "prim %u: material out of range", i);
+    }
+    for (uint32_t i = 0; i < 2 * s->n_lenses; ++i) {
+        uint32_t p = s->lens_spheres[i];
+        if (p >= s->n_prims || s->prim_type[p] != RTX_PRIM_SPHERE) return fail(RTX_ERR_INVALID, "lens %u: inner sphere id invalid", i / 2);
+    }
+    for (uint32_t i = 0; i < s->n_leaf_refs; ++i)
+        if (s->leaf_refs[i] >= s->n_shapes) return fail(RTX_ERR_INVALID, "leaf ref %u out of range", i);
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        const rtx_texture& t = s->textures[i];
+        if (t.width == 0 || t.height == 0 || t.offset + (uint64_t)t.width * t.height * 3 > s->n_texel_bytes)
+            return fail(RTX_ERR_INVALID, "texture %u outside the texel buffer", i);
+    }
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        const rtx_material& m = s->materials[i];
+        const rtx_sampler* f[6] = {&m.color_fn, &m.ns_fn, &m.ni_fn, &m.transparency_fn, &m.metalness_fn, &m.smoothness_fn};
+        for (int k = 0; k < 6; ++k) {
+            if (f[k]->kind > RTX_SAMPLER_TEXTURE_DOUBLE) return fail(RTX_ERR_INVALID, "material %u: unknown sampler", i);
+            if ((f[k]->kind == RTX_SAMPLER_TEXTURE_VEC3 || f[k]->kind == RTX_SAMPLER_TEXTURE_DOUBLE) && f[k]->texture >= s->n_textures)
+                return fail(RTX_ERR_INVALID, "material %u: texture out of range", i);
+        }
+    }
+    for (uint32_t i = 0; i < s->n_lights; ++i)
+        if (s->lights[i].kind > RTX_LIGHT_SQUARE) return fail(RTX_ERR_INVALID, "light %u: unknown kind", i);
+    std::vector<uint8_t> seen(s->n_branches, 0);
+    int depth = validate_tree(s, s->kd_root, 0, seen);
+    if (depth < 0) return fail(RTX_ERR_INVALID, "KD tree is malformed (index out of range, cycle, or deeper than 64)");
+    if (depth > kStack) return fail(RTX_ERR_LIMIT, "KD tree depth %d exceeds the traversal stack (%d)", depth, kStack);
+    *kd_depth = (uint32_t)depth;
+    return RTX_OK;
+}
+
+inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+struct StageTimer {
+    bool on;
+    hipStream_t stream;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(bool on, hipStream_t s) : on(on), stream(s)
+    {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+    }
+    ~StageTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    void begin() { if (on) (void)hipEventRecord(a, stream); }
+    void end(double* acc)
+    {
+        if (!on) return;
+        (void)hipEventRecord(b, stream);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        *acc += ms;
+    }
+};
+
+int read_count(rtx_scene* sc, int which, uint32_t* out)
+{
+    HIP_TRY(hipMemcpyAsync(sc->ws.host_counts + which, sc->ws.counts + which, sizeof(uint32_t), hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    *out = sc->ws.host_counts[which];
+    return RTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtx_last_error(void) { return g_error.c_str(); }
+
+int rtx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rtx_init(int device)
+{
+    int n = rtx_device_count();
+    if (n <= 0) return fail(RTX_ERR_NO_GPU, "no HIP device is visible");
+    if (device >= n) return fail(RTX_ERR_INVALID, "device %d of %d", device, n);
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    HIP_TRY(hipGetDeviceProperties(&prop, cur));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RTX_ERR_NO_GPU, "device %d is %s; this library is built for gfx950 only", cur, prop.gcnArchName);
+    return RTX_OK;
+}
+
+int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
+{
+    if (!out) return fail(RTX_ERR_INVALID, "null output handle");
+    *out = nullptr;
+    uint32_t kd_depth = 0;
+    int rc = validate_scene(s, &kd_depth);
+    if (rc != RTX_OK) return rc;
+    if (rtx_device_count() <= 0) return fail(RTX_ERR_NO_GPU, "no HIP device is visible");
+
+    rtx_scene* sc = new rtx_scene();
+    sc->kd_depth = kd_depth;
+    (void)hipGetDevice(&sc->device);
+    DScene& d = sc->d;
+    std::memset(&d, 0, sizeof d);
+    d.root = s->kd_root;
+    d.n_branches = s->n_branches; d.n_leaves = s->n_leaves; d.n_leaf_refs = s->n_leaf_refs;
+    d.n_shapes = s->n_shapes; d.n_prims = s->n_prims; d.n_lights = s->n_lights;
+    d.n_materials = s->n_materials; d.n_textures = s->n_textures;
+
+    std::vector<Branch> branches(s->n_branches);
+    for (uint32_t i = 0; i < s->n_branches; ++i) {
+        Branch& b = branches[i];
+        std::memset(&b, 0, sizeof b);
+        for (int k = 0; k < 3; ++k) { b.bmin[k] = s->branch_min[3 * i + k]; b.bmax[k] = s->branch_max[3 * i + k]; }
+        b.value = s->branch_value[i]; b.axis = s->branch_axis[i];
+        b.lesser = s->branch_lesser[i]; b.greater = s->branch_greater[i];
+    }
+    std::vector<uint2> leaves(s->n_leaves);
+    for (uint32_t i = 0; i < s->n_leaves; ++i) leaves[i] = make_uint2(s->leaf_first[i], s->leaf_count[i]);
+    std::vector<PrimBox> boxes(s->n_prims);
+    std::vector<uint32_t> info(s->n_prims);
+    for (uint32_t i = 0; i < s->n_prims; ++i) {
+        for (int k = 0; k < 3; ++k) { boxes[i].bmin[k] = s->prim_aabb_min[3 * i + k]; boxes[i].bmax[k] = s->prim_aabb_max[3 * i + k]; }
+        info[i] = (uint32_t)s->prim_type[i] | (s->prim_index[i] << 2);
+    }
+
+    DeviceBuffers& B = sc->buffers;
+    hipError_t e = hipSuccess;
+    auto up = [&](auto host, size_t count, auto out_ptr) { if (e == hipSuccess) e = B.upload(host, count, out_ptr); };
+    up(branches.data(), branches.size(), &d.branches);
+    up(leaves.data(), leaves.size(), &d.leaves);
+    up(s->leaf_refs, (size_t)s->n_leaf_refs, &d.leaf_refs);
+    up(boxes.data(), boxes.size(), &d.prim_box);
+    up(info.data(), info.size(), &d.prim_info);
+    up(s->prim_material, (size_t)s->n_prims, &d.prim_material);
+    up(s->tri_position, (size_t)s->n_triangles * 9, &d.tri_pos);
+    up(s->tri_normal, (size_t)s->n_triangles * 9, &d.tri_nrm);
+    up(s->tri_uv, (size_t)s->n_triangles * 6, &d.tri_uv);
+    up(s->sphere_center, (size_t)s->n_spheres * 3, &d.sph_center);
+    up(s->sphere_radius, (size_t)s->n_spheres, &d.sph_radius);
+    up(s->sphere_r2, (size_t)s->n_spheres, &d.sph_r2);
+    up(s->sphere_normal_matrix, (size_t)s->n_spheres * 16, &d.sph_nmat);
+    up(s->lens_spheres, (size_t)s->n_lenses * 2, &d.lens_spheres);
+    up(s->materials, (size_t)s->n_materials, &d.materials);
+    up(s->textures, (size_t)s->n_textures, &d.textures);
+    up(s->texels, (size_t)s->n_texel_bytes, &d.texels);
+    up(s->lights, (size_t)s->n_lights, &d.lights);
+    if (e != hipSuccess) {
+        delete sc;
+        return fail(RTX_ERR_DEVICE, "scene upload: %s", hipGetErrorString(e));
+    }
+    *out = sc;
+    return RTX_OK;
+}
+
+int rtx_scene_set_stream(rtx_scene* sc, void* hip_stream)
+{
+    if (!sc) return fail(RTX_ERR_INVALID, "null scene");
+    sc->stream = static_cast<hipStream_t>(hip_stream);
+    return RTX_OK;
+}
+
+void rtx_scene_destroy(rtx_scene* sc) { delete sc; }
+
+int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* direction, size_t n, uint32_t flags,
+                      int32_t* prim, double* depth, double* position, double* normal, double* uv, double* bary,
+                      uint32_t* leaf_count, uint64_t* leaf_hash, uint32_t* leaf_seq, uint32_t leaf_seq_cap,
+                      uint32_t* counters)
+{
+    if (!sc || !origin || !direction || !prim || !depth) return fail(RTX_ERR_INVALID, "null argument");
+    if (n == 0) return RTX_OK;
+    if (n > 0x7fffffffu) return fail(RTX_ERR_LIMIT, "at most 2^31-1 rays per call");
+    DeviceBuffers tmp;
+    const double *d_o = nullptr, *d_d = nullptr;
+    HIP_TRY(tmp.upload(origin, n * 3, &d_o));
+    HIP_TRY(tmp.upload(direction, n * 3, &d_d));
+    auto dalloc = [&](size_t bytes, void** p) -> hipError_t {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) tmp.ptrs.push_back(*p);
+        return e;
+    };
+    int32_t* d_prim = nullptr; double* d_depth = nullptr;
+    double *d_pos = nullptr, *d_nrm = nullptr, *d_uv = nullptr, *d_bary = nullptr;
+    uint32_t *d_lc = nullptr, *d_seq = nullptr, *d_ctr = nullptr;
+    unsigned long long* d_lh = nullptr;
+    HIP_TRY(dalloc(n * 4, (void**)&d_prim));
+    HIP_TRY(dalloc(n * 8, (void**)&d_depth));
+    if (position) HIP_TRY(dalloc(n * 24, (void**)&d_pos));
+    if (normal) HIP_TRY(dalloc(n * 24, (void**)&d_nrm));
+    if (uv) HIP_TRY(dalloc(n * 16, (void**)&d_uv));
+    if (bary) HIP_TRY(dalloc(n * 24, (void**)&d_bary));
+    if (leaf_count) HIP_TRY(dalloc(n * 4, (void**)&d_lc));
+    if (leaf_hash) HIP_TRY(dalloc(n * 8, (void**)&d_lh));
+    if (leaf_seq && leaf_seq_cap) {
+        HIP_TRY(dalloc(n * (size_t)leaf_seq_cap * 4, (void**)&d_seq));
+        HIP_TRY(hipMemcpy(d_seq, leaf_seq, n * (size_t)leaf_seq_cap * 4, hipMemcpyHostToDevice));
+    }
+    if (counters) HIP_TRY(dalloc(n * 24, (void**)&d_ctr));
+    hipLaunchKernelGGL(k_trace_api, grid_for(n), dim3(kBlock), 0, sc->stream, sc->d, d_o, d_d, (uint32_t)n,
+                       (flags & RTX_FLAG_LINEAR_SCAN) ? 1u : 0u, d_prim, d_depth, d_pos, d_nrm, d_uv, d_bary, d_lc, d_lh,
+                       d_seq, leaf_seq_cap, d_ctr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    HIP_TRY(hipMemcpy(prim, d_prim, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(depth, d_depth, n * 8, hipMemcpyDeviceToHost));
+    if (position) HIP_TRY(hipMemcpy(position, d_pos, n * 24, hipMemcpyDeviceToHost));
+    if (normal) HIP_TRY(hipMemcpy(normal, d_nrm, n * 24, hipMemcpyDeviceToHost));
+    if (uv) HIP_TRY(hipMemcpy(uv, d_uv, n * 16, hipMemcpyDeviceToHost));
+    if (bary) HIP_TRY(hipMemcpy(bary, d_bary, n * 24, hipMemcpyDeviceToHost));
+    if (leaf_count) HIP_TRY(hipMemcpy(leaf_count, d_lc, n * 4, hipMemcpyDeviceToHost));
+    if (leaf_hash) HIP_TRY(hipMemcpy(leaf_hash, d_lh, n * 8, hipMemcpyDeviceToHost));
+    if (d_seq) HIP_TRY(hipMemcpy(leaf_seq, d_seq, n * (size_t)leaf_seq_cap * 4, hipMemcpyDeviceToHost));
+    if (counters) HIP_TRY(hipMemcpy(counters, d_ctr, n * 24, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const double* oz, const double* dx,
+                        const double* dy, const double* dz, uint32_t n, uint32_t flags, int32_t* hit_prim,
+                        double* hit_depth, bool count)
+{
+    uint32_t linear = (flags & RTX_FLAG_LINEAR_SCAN) ? 1u : 0u;
+    Counters g;
+    g.c = count ? sc->ws.work : nullptr;
+    if (count)
+        hipLaunchKernelGGL(k_trace_pool<true>, grid_for(n), dim3(kBlock), 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, n,
+                           linear, hit_prim, hit_depth, g);
+    else
+        hipLaunchKernelGGL(k_trace_pool<false>, grid_for(n), dim3(kBlock), 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, n,
+                           linear, hit_prim, hit_depth, g);
+    HIP_TRY(hipGetLastError());
+    return RTX_OK;
+}
+
+int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rtx_stats* stats)
+{
+    if (!sc || !rd || !accum) return fail(RTX_ERR_INVALID, "null argument");
+    if (rd->integrator > RTX_INTEGRATOR_WHITTED) return fail(RTX_ERR_INVALID, "unknown integrator");
+    if (rd->width < 2 || rd->height < 2) return fail(RTX_ERR_INVALID, "frame must be at least 2x2");
+    if (rd->tile_w == 0 || rd->tile_h == 0 || rd->tile_x0 + (uint64_t)rd->tile_w > rd->width ||
+        rd->tile_y0 + (uint64_t)rd->tile_h > rd->height)
+        return fail(RTX_ERR_INVALID, "tile outside the frame");
+    uint32_t n = rd->pixel_multisample_n ? rd->pixel_multisample_n : 1;
+    if (n > 64) return fail(RTX_ERR_LIMIT, "pixel_multisample_n > 64");
+    const bool whitted = rd->integrator == RTX_INTEGRATOR_WHITTED;
+    const bool count_work = (rd->flags & RTX_FLAG_COUNTERS) != 0;
+
+    RenderParams p;
+    std::memset(&p, 0, sizeof p);
+    p.d = *rd;
+    p.d.pixel_multisample_n = n;
+    p.n = n;
+    p.blocks_w = (rd->tile_w + 7) / 8;
+    uint32_t blocks_h = (rd->tile_h + 7) / 8;
+    uint64_t padded_pixels = (uint64_t)p.blocks_w * blocks_h * 64;
+    uint32_t nn = n * n;
+    uint32_t shadow_per_hit = 0;
+    if (whitted && !(rd->flags & RTX_FLAG_NO_LIGHTING)) {
+        std::vector<rtx_light> lights(sc->d.n_lights);
+        if (!lights.empty()) HIP_TRY(hipMemcpy(lights.data(), sc->d.lights, lights.size() * sizeof(rtx_light), hipMemcpyDeviceToHost));
+        for (const rtx_light& l : lights)
+            shadow_per_hit += l.multisample ? rd->light_multisample_n * rd->light_multisample_n : 1u;
+    }
+    p.shadow_per_hit = shadow_per_hit;
+
+    // chunk size: whole 8x8 pixel blocks, bounded by the path budget
+    size_t max_paths = 8u << 20;
+    if (const char* env = std::getenv("RTX_MAX_PATHS")) { long v = std::atol(env); if (v >= 64) max_paths = (size_t)v; }
+    uint64_t pixels_per_chunk = std::max<uint64_t>(64, (max_paths / nn) / 64 * 64);
+    pixels_per_chunk = std::min<uint64_t>(pixels_per_chunk, padded_pixels);
+    // the mirror extension can double the queue at every level
+    size_t fan = (whitted && (rd->flags & RTX_FLAG_WHITTED_REFLECT)) ? 2 : 1;
+    size_t cap = (size_t)pixels_per_chunk * nn;
+    size_t queue_cap = cap;
+    if (fan > 1) {
+        size_t growth = 1;
+        for (uint32_t l = 0; l < std::min<uint32_t>(rd->max_depth, 4); ++l) growth *= 2;
+        queue_cap = cap * growth;
+    }
+    int rc = ensure_workspace(sc, queue_cap, whitted ? queue_cap * std::max<uint32_t>(shadow_per_hit, 1) : 0);
+    if (rc != RTX_OK) return rc;
+    Workspace& w = sc->ws;
+    hipStream_t st = sc->stream;
+    p.queue_cap = (uint32_t)std::min<size_t>(w.capacity, 0xffffffffu);
+    p.shadow_cap = (uint32_t)std::min<size_t>(w.shadow_capacity, 0xffffffffu);
+
+    rtx_stats local;
+    std::memset(&local, 0, sizeof local);
+    StageTimer timer(stats != nullptr, st);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, st)); }
+    if (count_work) HIP_TRY(hipMemsetAsync(w.work, 0, 6 * sizeof(unsigned long long), st));
+
+    for (uint32_t pass = rd->first_pass; pass < rd->first_pass + rd->passes; ++pass) {
+        p.pass = pass;
+        for (uint64_t t0 = 0; t0 < padded_pixels; t0 += pixels_per_chunk) {
+            p.chunk_t0 = (uint32_t)t0;
+            p.chunk_pixels = (uint32_t)std::min<uint64_t>(pixels_per_chunk, padded_pixels - t0);
+            size_t slots = (size_t)p.chunk_pixels * nn;
+            HIP_TRY(hipMemsetAsync(w.sample, 0, slots * 3 * sizeof(double), st));
+            HIP_TRY(hipMemsetAsync(w.counts, 0, 4 * sizeof(uint32_t), st));
+            timer.begin();
+            hipLaunchKernelGGL(k_generate, grid_for(slots), dim3(kBlock), 0, st, p, w.q[0], w.counts + 2);
+            HIP_TRY(hipGetLastError());
+            timer.end(&local.ms_generate);
+            uint32_t count = 0;
+            rc = read_count(sc, 2, &count);
+            if (rc != RTX_OK) return rc;
+            int cur = 0;
+            uint32_t level = 0;
+            while (count > 0) {
+                if (count > queue_cap) return fail(RTX_ERR_LIMIT, "ray queue overflow (%u > %zu)", count, queue_cap);
+                RayQueue& q = w.q[cur];
+                RayQueue& nq = w.q[cur ^ 1];
+                local.max_queue = std::max(local.max_queue, count);
+                if (level == 0) local.rays_primary += count; else local.rays_secondary += count;
+                timer.begin();
+                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, count, rd->flags, q.hit_prim, q.hit_depth, count_work);
+                if (rc != RTX_OK) return rc;
+                timer.end(&local.ms_traverse);
+                local.traverse_launches++;
+                HIP_TRY(hipMemsetAsync(w.counts, 0, 2 * sizeof(uint32_t), st));
+                if (!whitted) {
+                    timer.begin();
+                    hipLaunchKernelGGL(k_shade_path, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, nq, w.counts + 0, w.sample);
+                    HIP_TRY(hipGetLastError());
+                    timer.end(&local.ms_shade);
+                } else {
+                    timer.begin();
+                    hipLaunchKernelGGL(k_shade_whitted_a, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
+                                       w.counts + 1, w.shadow_index, w.sample);
+                    HIP_TRY(hipGetLastError());
+                    timer.end(&local.ms_shade);
+                    uint32_t nshadow = 0;
+                    rc = read_count(sc, 1, &nshadow);
+                    if (rc != RTX_OK) return rc;
+                    if (nshadow > w.shadow_capacity) return fail(RTX_ERR_LIMIT, "shadow queue overflow");
+                    if (nshadow > 0) {
+                        local.rays_shadow += nshadow;
+                        timer.begin();
+                        rc = launch_trace(sc, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, nshadow, rd->flags, nullptr,
+                                          w.sq.hit_depth, count_work);
+                        if (rc != RTX_OK) return rc;
+                        timer.end(&local.ms_shadow);
+                        local.traverse_launches++;
+                    }
+                    timer.begin();
+                    hipLaunchKernelGGL(k_shade_whitted_b, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
+                                       w.shadow_index, nq, w.counts + 0, w.sample);
+                    HIP_TRY(hipGetLastError());
+                    timer.end(&local.ms_shade);
+                }
+                rc = read_count(sc, 0, &count);
+                if (rc != RTX_OK) return rc;
+                cur ^= 1;
+                ++level;
+            }
+            timer.begin();
+            hipLaunchKernelGGL(k_resolve, grid_for(p.chunk_pixels), dim3(kBlock), 0, st, p, w.sample, accum);
+            HIP_TRY(hipGetLastError());
+            timer.end(&local.ms_resolve);
+        }
+    }
+    if (count_work) {
+        HIP_TRY(hipMemcpyAsync(w.host_work, w.work, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    }
+    if (stats) HIP_TRY(hipEventRecord(ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (stats) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        local.ms_total = ms;
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+        if (count_work) {
+            local.branch_visits = w.host_work[0]; local.leaf_visits = w.host_work[1]; local.aabb_tests = w.host_work[2];
+            local.triangle_tests = w.host_work[3]; local.sphere_tests = w.host_work[4]; local.hits_accepted = w.host_work[5];
+        }
+        *stats = local;
+    }
+    return RTX_OK;
+}
+
+int rtx_render(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rtx_stats* stats)
+{
+    if (!sc || !rd || !accum) return fail(RTX_ERR_INVALID, "null argument");
+    size_t bytes = (size_t)rd->tile_w * rd->tile_h * 3 * sizeof(float);
+    if (bytes == 0) return fail(RTX_ERR_INVALID, "empty tile");
+    float* d_accum = nullptr;
+    HIP_TRY(hipMalloc(&d_accum, bytes));
+    int rc = RTX_OK;
+    hipError_t e = hipMemcpy(d_accum, accum, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(RTX_ERR_DEVICE, "upload of accum: %s", hipGetErrorString(e));
+    if (rc == RTX_OK) rc = rtx_render_device(sc, rd, d_accum, stats);
+    if (rc == RTX_OK) {
+        e = hipMemcpy(accum, d_accum, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RTX_ERR_DEVICE, "download of accum: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_accum);
+    return rc;
+}
+
+double rtx_uniform(uint64_t seed, uint32_t frame, uint32_t pixel, uint32_t sample, uint32_t branch, uint32_t draw_index)
+{
+    // host evaluation of the device generator (same integer arithmetic)
+    uint32_t c0 = pixel, c1 = sample, c2 = branch, c3 = draw_index >> 2;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (frame * 0x9E3779B9u);
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    uint32_t o[4] = {c0, c1, c2, c3};
+    return (double)o[draw_index & 3u] / 4294967295.0;
+}
+
+}  // extern "C"

@@ -1,0 +1,526 @@
+// rtx_kernels.hpp -- the wavefront pipeline's kernels (gfx950, wave64).
+//
+//   k_generate        per-pixel lambda up to the camera ray (Raytracer.cpp:676-700)
+//   k_trace_pool      shootRay for a ray queue: KD traversal + leaf scans
+//   k_trace_api       the same for caller-supplied rays, with leaf sequences/counters
+//   k_shade_path      pathTrace body (Raytracer.cpp:217-355), one level per launch
+//   k_shade_whitted_a rayTrace up to the light rays (Raytracer-Noah-Desktop.cpp:452-490)
+//   k_shade_whitted_b rayTrace after the shadow rays returned (:490-553)
+//   k_resolve         drawBuffer[pixel] += colorAcum / (n*n)  (Raytracer.cpp:705-710)
+//
+// The reference recurses; here each recursion level is one pass over a queue of
+// rays that carry their accumulated weight, and every queue is compacted with
+// wave64 ballot / mbcnt prefix sums and one atomic per wave.
+#pragma once
+#include "rtx_device.hpp"
+
+namespace rtx {
+
+constexpr int kBlock = 256;             // threads per workgroup (4 waves)
+constexpr int kStack = 24;              // per-lane KD stack entries (tree depth is capped at 21, KDTree.cpp:69)
+
+// ---- ray queue (SoA, resident in HBM) ---------------------------------------------------
+struct RayQueue {
+    double *ox, *oy, *oz, *dx, *dy, *dz;    // Ray (direction already normalised by Ray::Ray)
+    double *wx, *wy, *wz;                   // weight this ray's radiance carries into its sample
+    double *ior;                            // currentIOR argument
+    uint32_t *slot;                         // sample slot the ray contributes to
+    uint32_t *layer;                        // recursion depth
+    uint32_t *branch, *counter;             // random stream (branch code, next draw index)
+    int32_t *hit_prim;                      // filled by k_trace_pool
+    double *hit_depth;
+};
+
+struct ShadowQueue {
+    double *ox, *oy, *oz, *dx, *dy, *dz;
+    double *hit_depth;
+};
+
+struct Counters { unsigned long long* c; };     // 6 global work counters, or null
+
+struct RenderParams {
+    rtx_render_desc d;
+    uint32_t chunk_t0;          // first padded pixel index of this chunk
+    uint32_t chunk_pixels;      // padded pixels in this chunk (multiple of 64)
+    uint32_t blocks_w;          // 8x8 pixel blocks per tile row
+    uint32_t pass;
+    uint32_t n;                 // pixel_multisample_n
+    uint32_t shadow_per_hit;    // sum over lights of samples
+    uint32_t queue_cap;         // entries a ray queue can hold; writes beyond are dropped and
+    uint32_t shadow_cap;        //   the host turns the overshooting count into RTX_ERR_LIMIT
+};
+
+// ---- wave64 compaction --------------------------------------------------------------------
+// Must be called by every lane of the wave.  Returns this lane's output index
+// (valid when pred) after reserving room for the wave with one atomic.
+RTX_DEV uint32_t wave_reserve(bool pred, uint32_t* counter, uint32_t per_item = 1)
+{
+    unsigned long long mask = __ballot(pred);
+    uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    if (prefix == 0 && pred) base = atomicAdd(counter, total * per_item);     // first set lane
+    int leader = mask ? (int)__builtin_ctzll(mask) : 0;
+    base = __shfl(base, leader);
+    return base + prefix * per_item;
+}
+
+// ---- traversal core -------------------------------------------------------------------------
+template <bool COUNT>
+struct Work {
+    uint32_t branch = 0, leaf = 0, aabb = 0, tri = 0, sph = 0, accepted = 0;
+    uint32_t leaf_count = 0;
+    unsigned long long leaf_hash = 14695981039346656037ull;
+};
+template <>
+struct Work<false> {};
+
+// rayHitListOfShapes (KDTree.cpp:206-220) over leaf references (or over all shapes
+// when refs == nullptr: the !KDTRACE path, Raytracer.cpp:117)
+template <bool COUNT>
+RTX_DEV void scan_refs(const DScene& s, const uint32_t* __restrict__ refs, uint32_t count, d3 o, d3 d, d3 inv,
+                       int32_t& best_prim, double& best_depth, Work<COUNT>& w)
+{
+    for (uint32_t k = 0; k < count; ++k) {
+        uint32_t prim = refs ? refs[k] : k;
+        const PrimBox* pb = s.prim_box + prim;
+        double tmin, tmax;
+        slab(ld3(pb->bmin), ld3(pb->bmax), o, inv, tmin, tmax);
+        if constexpr (COUNT) w.aabb++;
+        if (tmin <= tmax && tmax >= 0.0) {
+            uint32_t info = s.prim_info[prim];
+            uint32_t type = info & 3u, idx = info >> 2;
+            double depth = kInf;
+            uint32_t rp = prim;
+            bool ok;
+            if (type == RTX_PRIM_TRIANGLE) {
+                if constexpr (COUNT) w.tri++;
+                ok = triangle_depth(s.tri_pos + 9 * (size_t)idx, o, d, depth);
+            } else if (type == RTX_PRIM_SPHERE) {
+                if constexpr (COUNT) w.sph++;
+                ok = sphere_t(ld3(s.sph_center + 3 * (size_t)idx), s.sph_r2[idx], o, d, depth);
+            } else {
+                if constexpr (COUNT) w.sph += 2;
+                ok = biconvex_depth(s, idx, o, d, depth, rp);
+            }
+            if (ok && depth < best_depth) {
+                if constexpr (COUNT) w.accepted++;
+                best_depth = depth;
+                best_prim = (int32_t)rp;
+            }
+        }
+    }
+}
+
+// traverseKDTree (KDTree.cpp:158-204) as an iterative walk: lesser subtree first,
+// the greater child is deferred on a per-lane stack kept in LDS (stack[level*kBlock]).
+template <bool COUNT>
+RTX_DEV void trace_lane(const DScene& s, d3 o, d3 d, bool linear, int32_t* stack, int32_t& best_prim,
+                        double& best_depth, Work<COUNT>& w, uint32_t* seq, uint32_t seq_cap)
+{
+    best_prim = -1;
+    best_depth = kInf;
+    d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    if (linear) { scan_refs<COUNT>(s, nullptr, s.n_shapes, o, d, inv, best_prim, best_depth, w); return; }
+    int sp = 0;
+    int32_t node = s.root;
+    for (;;) {
+        if (node >= 0) {
+            const Branch* b = s.branches + node;
+            double tmin, tmax;
+            slab(ld3(b->bmin), ld3(b->bmax), o, inv, tmin, tmax);
+            if constexpr (COUNT) w.branch++;
+            if (tmin < tmax && tmax >= 0.0) {
+                int axis = b->axis;
+                double value = b->value;
+                double oa = pick(o, axis), da = pick(d, axis);
+                double enter = oa + (da * tmin);
+                double exit_ = oa + (da * tmax);
+                int32_t lesser = b->lesser, greater = b->greater;
+                bool only_lesser, only_greater;
+                if (enter <= value) { only_lesser = exit_ < value; only_greater = false; }
+                else { only_greater = exit_ > value; only_lesser = false; }
+                if (only_greater) { node = greater; }
+                else {
+                    if (!only_lesser) { stack[sp * kBlock] = greater; ++sp; }
+                    node = lesser;
+                }
+                continue;
+            }
+        } else {
+            uint32_t leaf = (uint32_t)~node;
+            if constexpr (COUNT) {
+                if (seq && w.leaf_count < seq_cap) seq[w.leaf_count] = leaf;
+                w.leaf_count++;
+                for (int b = 0; b < 4; ++b) { w.leaf_hash ^= (leaf >> (8 * b)) & 0xffu; w.leaf_hash *= 1099511628211ull; }
+                w.leaf++;
+            }
+            uint2 fc = s.leaves[leaf];
+            scan_refs<COUNT>(s, s.leaf_refs + fc.x, fc.y, o, d, inv, best_prim, best_depth, w);
+        }
+        if (sp == 0) break;
+        --sp;
+        node = stack[sp * kBlock];
+    }
+}
+
+RTX_DEV void add_counters(Counters g, const Work<true>& w)
+{
+    if (!g.c) return;
+    atomicAdd(g.c + 0, (unsigned long long)w.branch); atomicAdd(g.c + 1, (unsigned long long)w.leaf);
+    atomicAdd(g.c + 2, (unsigned long long)w.aabb); atomicAdd(g.c + 3, (unsigned long long)w.tri);
+    atomicAdd(g.c + 4, (unsigned long long)w.sph); atomicAdd(g.c + 5, (unsigned long long)w.accepted);
+}
+RTX_DEV void add_counters(Counters, const Work<false>&) {}
+
+// shootRay for caller-supplied rays (rtx_trace_closest)
+__global__ void __launch_bounds__(kBlock)
+k_trace_api(DScene s, const double* __restrict__ origin, const double* __restrict__ direction, uint32_t n,
+            uint32_t linear, int32_t* prim, double* depth, double* position, double* normal, double* uv, double* bary,
+            uint32_t* leaf_count, unsigned long long* leaf_hash, uint32_t* leaf_seq, uint32_t leaf_seq_cap,
+            uint32_t* counters)
+{
+    __shared__ int32_t stack[kStack * kBlock];
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Ray r = make_ray(ld3(origin + 3 * (size_t)i), ld3(direction + 3 * (size_t)i));
+    Work<true> w;
+    int32_t bp; double bd;
+    trace_lane<true>(s, r.o, r.d, linear != 0, stack + threadIdx.x, bp, bd, w,
+                     leaf_seq ? leaf_seq + (size_t)i * leaf_seq_cap : nullptr, leaf_seq_cap);
+    prim[i] = bp;
+    depth[i] = bd;
+    Hit h;
+    h.position = mk(0, 0, 0); h.normal = mk(0, 0, 0); h.bary = mk(0, 0, 0); h.u = 0; h.v = 0;
+    if (bp >= 0) prim_full(s, (uint32_t)bp, r.o, r.d, h);
+    if (position) { position[3 * (size_t)i] = h.position.x; position[3 * (size_t)i + 1] = h.position.y; position[3 * (size_t)i + 2] = h.position.z; }
+    if (normal) { normal[3 * (size_t)i] = h.normal.x; normal[3 * (size_t)i + 1] = h.normal.y; normal[3 * (size_t)i + 2] = h.normal.z; }
+    if (uv) { uv[2 * (size_t)i] = h.u; uv[2 * (size_t)i + 1] = h.v; }
+    if (bary) { bary[3 * (size_t)i] = h.bary.x; bary[3 * (size_t)i + 1] = h.bary.y; bary[3 * (size_t)i + 2] = h.bary.z; }
+    if (leaf_count) leaf_count[i] = w.leaf_count;
+    if (leaf_hash) leaf_hash[i] = w.leaf_hash;
+    if (counters) {
+        uint32_t* c = counters + 6 * (size_t)i;
+        c[0] = w.branch; c[1] = w.leaf; c[2] = w.aabb; c[3] = w.tri; c[4] = w.sph; c[5] = w.accepted;
+    }
+}
+
+// shootRay for a queue: reads (o, d), writes (hit_prim, hit_depth)
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock)
+k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
+             const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
+             uint32_t n, uint32_t linear, int32_t* hit_prim, double* hit_depth, Counters g)
+{
+    __shared__ int32_t stack[kStack * kBlock];
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    d3 o = mk(ox[i], oy[i], oz[i]), d = mk(dx[i], dy[i], dz[i]);
+    Work<COUNT> w;
+    int32_t bp; double bd;
+    trace_lane<COUNT>(s, o, d, linear != 0, stack + threadIdx.x, bp, bd, w, nullptr, 0);
+    if (hit_prim) hit_prim[i] = bp;
+    hit_depth[i] = bd;
+    add_counters(g, w);
+}
+
+// ---- pixel <-> slot mapping ------------------------------------------------------------------
+// Padded pixel index t walks the tile in 8x8 blocks so that a wave's 64 rays are neighbours.
+RTX_DEV bool pixel_of(const RenderParams& p, uint32_t t, uint32_t& x, uint32_t& y)
+{
+    uint32_t block = t >> 6, inb = t & 63u;
+    uint32_t bx = block % p.blocks_w, by = block / p.blocks_w;
+    uint32_t lx = bx * 8 + (inb & 7u), ly = by * 8 + (inb >> 3);
+    x = p.d.tile_x0 + lx; y = p.d.tile_y0 + ly;
+    return lx < p.d.tile_w && ly < p.d.tile_h;
+}
+
+RTX_DEV void push_ray(const RayQueue& q, uint32_t j, const Ray& r, d3 w, double ior, uint32_t slot, uint32_t layer,
+                      uint32_t branch, uint32_t counter)
+{
+    q.ox[j] = r.o.x; q.oy[j] = r.o.y; q.oz[j] = r.o.z;
+    q.dx[j] = r.d.x; q.dy[j] = r.d.y; q.dz[j] = r.d.z;
+    q.wx[j] = w.x; q.wy[j] = w.y; q.wz[j] = w.z;
+    q.ior[j] = ior; q.slot[j] = slot; q.layer[j] = layer; q.branch[j] = branch; q.counter[j] = counter;
+}
+
+// camera rays of one chunk (Raytracer.cpp:676-700); one thread per sample slot
+__global__ void __launch_bounds__(kBlock)
+k_generate(RenderParams p, RayQueue q, uint32_t* count)
+{
+    uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t nn = p.n * p.n;
+    uint32_t total = p.chunk_pixels * nn;
+    bool valid = false;
+    Ray ray;
+    if (slot < total) {
+        uint32_t t = p.chunk_t0 + slot / nn, sub = slot % nn;
+        uint32_t x, y;
+        if (pixel_of(p, t, x, y)) {
+            valid = true;
+            uint32_t sx = sub / p.n + 1, sy = sub % p.n + 1;
+            const rtx_camera& c = p.d.camera;
+            double nx = ((double)x / (double)p.d.width) - 0.5;
+            double ny = ((double)y / (double)p.d.height) - 0.5;
+            d3 eye = ld3(c.eye);
+            d3 on_screen = (((ld3(c.right) * nx) + (ld3(c.up) * ny)) + eye) + (ld3(c.forward) * c.focal);
+            double cx = 1.0 / ((double)p.d.width - 1.0), cy = 1.0 / ((double)p.d.height - 1.0);
+            double offx = (double)sx * (cx / (double)(p.n + 1));
+            double offy = (double)sy * (cy / (double)(p.n + 1));
+            d3 v = normalize3((on_screen + mk(offx, offy, 0.0)) - eye);
+            ray = make_ray(eye, v);
+        }
+    }
+    uint32_t j = wave_reserve(valid, count);
+    if (valid && j < p.queue_cap) push_ray(q, j, ray, mk(1.0, 1.0, 1.0), 1.0, slot, 0u, 0u, 0u);
+}
+
+RTX_DEV void sample_add(double* sample, uint32_t slot, d3 v)
+{
+    // a sample can receive terms from several rays of one launch only with the mirror
+    // extension of the Whitted integrator, hence atomics
+    unsafeAtomicAdd(sample + 3 * (size_t)slot + 0, v.x);
+    unsafeAtomicAdd(sample + 3 * (size_t)slot + 1, v.y);
+    unsafeAtomicAdd(sample + 3 * (size_t)slot + 2, v.z);
+}
+
+RTX_DEV Rng ray_rng(const RenderParams& p, const RayQueue& q, uint32_t i, uint32_t slot)
+{
+    uint32_t nn = p.n * p.n;
+    uint32_t t = p.chunk_t0 + slot / nn, sub = slot % nn;
+    uint32_t x, y;
+    pixel_of(p, t, x, y);
+    Rng r;
+    r.seed = p.d.seed; r.frame = p.d.frame; r.pixel = x + y * p.d.width;
+    r.sample = p.pass * nn + sub; r.branch = q.branch[i]; r.counter = q.counter[i];
+    return r;
+}
+
+// ---- pathTrace, one recursion level (Raytracer.cpp:217-355) -------------------------------------
+// The reference's result is `weight-product * terminal radiance`: refraction returns the
+// child's radiance unchanged (:272) and a bounce returns ctSpecular + kD*diffuse, both
+// linear in the child's radiance (:302-348).  Each ray therefore carries the product of
+// the per-level factors and the terminal value is added once to its sample.
+__global__ void __launch_bounds__(kBlock)
+k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, RayQueue next, uint32_t* next_count, double* sample)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool spawn = false;
+    Ray child; d3 cw = mk(0, 0, 0); double cior = 1.0; uint32_t slot = 0, layer = 0, cbranch = 0, ccounter = 0;
+    if (i < n) {
+        slot = q.slot[i]; layer = q.layer[i];
+        d3 w = mk(q.wx[i], q.wy[i], q.wz[i]);
+        d3 clear = ld3(p.d.clear_color);
+        int32_t prim = q.hit_prim[i];
+        if (prim < 0) {
+            sample_add(sample, slot, w * (clear * 0.1));
+        } else {
+            d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
+            d3 inv_dir = -d;
+            Hit h;
+            prim_full(s, (uint32_t)prim, o, d, h);
+            const rtx_material& m = s.materials[s.prim_material[prim]];
+            if (p.d.flags & RTX_FLAG_BASIC) {
+                sample_add(sample, slot, w * material_color(s, m, h.u, h.v));
+            } else {
+                double trans = sample_scalar(s, m.transparency_fn, m.transparency, h.u, h.v);
+                double smooth = sample_scalar(s, m.smoothness_fn, m.smoothness, h.u, h.v);
+                double metal = sample_scalar(s, m.metalness_fn, m.metalness, h.u, h.v);
+                Rng rng = ray_rng(p, q, i, slot);
+                double transparency_decider = rng_next(rng);
+                double reflectance_decider = rng_next(rng);
+                (void)rng_next(rng);                                // specularDecider (:241)
+                bool entering = is_entering(h.normal, inv_dir);
+                d3 emission = ld3(m.emission);
+                if (!(emission.x == 0.0 && emission.y == 0.0 && emission.z == 0.0)) {
+                    sample_add(sample, slot, w * emission);
+                } else {
+                    double ni = sample_scalar(s, m.ni_fn, m.ni, h.u, h.v);
+                    d3 dir, pos;
+                    if (transparency_decider < trans) {
+                        dir = normalize3(refraction_ray(normalize3(h.normal), normalize3(d), ni, entering));
+                        pos = h.position + ((h.normal * (entering ? -1.0 : 1.0)) * p.d.bias);
+                        child = make_ray(pos, dir);
+                        cw = w;
+                    } else {
+                        if (reflectance_decider < smooth) {
+                            dir = mirror_direction(d, h.normal);
+                        } else {
+                            // randomHemisphericalVector (:73-80)
+                            d3 nn = normalize3(h.normal);
+                            d3 out;
+                            do {
+                                double a = (rng_next(rng) * 2.0) - 1.0;
+                                double b = (rng_next(rng) * 2.0) - 1.0;
+                                double c = (rng_next(rng) * 2.0) - 1.0;
+                                out = normalize3(mk(a, b, c));
+                            } while (dot(nn, out) < 0.0);
+                            dir = normalize3(out);
+                        }
+                        pos = h.position + (h.normal * p.d.bias);
+                        child = make_ray(pos, dir);
+                        double f = fabs((1.0 - ni) / (1.0 + ni));
+                        d3 F0a = mk(f, f, f);
+                        F0a = F0a * F0a;
+                        d3 matC = material_color(s, m, h.u, h.v);
+                        d3 F0 = (F0a * (1.0 - metal)) + (matC * metal);
+                        d3 kS;
+                        d3 one = mk(1.0, 1.0, 1.0);
+                        d3 spec = cook_torrance(inv_dir, child.d, h.normal, smooth, one, F0, kS);
+                        double diff = dot(dir, h.normal);
+                        d3 kD = mk(1.0 - kS.x, 1.0 - kS.y, 1.0 - kS.z) * (1.0 - metal);
+                        d3 diffuse = (one * diff) * matC;
+                        cw = w * (spec + (kD * diffuse));
+                    }
+                    cior = ni; cbranch = rng.branch; ccounter = rng.counter;
+                    if (layer + 1 > p.d.max_depth) sample_add(sample, slot, cw * (clear * 0.1));   // :220-222
+                    else spawn = true;
+                }
+            }
+        }
+    }
+    uint32_t j = wave_reserve(spawn, next_count);
+    if (spawn && j < p.queue_cap) push_ray(next, j, child, cw, cior, slot, layer + 1, cbranch, ccounter);
+}
+
+// ---- rayTrace (Raytracer-Noah-Desktop.cpp:452-564), first half: emit the light rays -----------------
+// Hit rays get shadow_per_hit consecutive shadow-queue entries; shadow_base[i] records where.
+__global__ void __launch_bounds__(kBlock)
+k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, uint32_t* shadow_count,
+                  uint32_t* shadow_base, double* sample)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool hit = false;
+    if (i < n) {
+        int32_t prim = q.hit_prim[i];
+        if (prim < 0) {
+            sample_add(sample, q.slot[i], mk(q.wx[i], q.wy[i], q.wz[i]) * ld3(p.d.clear_color));
+        } else {
+            hit = true;
+        }
+    }
+    bool emit = hit && p.shadow_per_hit > 0 && !(p.d.flags & RTX_FLAG_NO_LIGHTING);
+    uint32_t base = wave_reserve(emit, shadow_count, p.shadow_per_hit);
+    if (i < n) shadow_base[i] = base;
+    if (emit && (unsigned long long)base + p.shadow_per_hit <= p.shadow_cap) {
+        d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
+        Hit h;
+        prim_full(s, (uint32_t)q.hit_prim[i], o, d, h);
+        uint32_t slot = q.slot[i];
+        Rng rng = ray_rng(p, q, i, slot);
+        d3 from = h.position + (h.normal * p.d.bias);
+        uint32_t k = base;
+        for (uint32_t li = 0; li < s.n_lights; ++li) {
+            const rtx_light& l = s.lights[li];
+            uint32_t samples = l.multisample ? p.d.light_multisample_n * p.d.light_multisample_n : 1u;
+            for (uint32_t sm = 0; sm < samples; ++sm, ++k) {
+                double u0 = 0.0, u1 = 0.0;
+                if (l.kind == RTX_LIGHT_SQUARE) { u0 = rng_next(rng); u1 = rng_next(rng); }
+                Ray lr = light_ray(l, from, u0, u1);
+                sq.ox[k] = lr.o.x; sq.oy[k] = lr.o.y; sq.oz[k] = lr.o.z;
+                sq.dx[k] = lr.d.x; sq.dy[k] = lr.d.y; sq.dz[k] = lr.d.z;
+            }
+        }
+        q.counter[i] = rng.counter;       // the refraction child continues this stream
+    }
+}
+
+// second half: direct lighting from the shadow results, blend, spawn children
+__global__ void __launch_bounds__(kBlock)
+k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, const uint32_t* shadow_base,
+                  RayQueue next, uint32_t* next_count, double* sample)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool spawn_t = false, spawn_r = false;
+    Ray child_t, child_r; d3 wt = mk(0, 0, 0), wr = mk(0, 0, 0);
+    double ni = 1.0; uint32_t slot = 0, layer = 0, branch = 0, counter = 0;
+    if (i < n && q.hit_prim[i] >= 0) {
+        slot = q.slot[i]; layer = q.layer[i]; branch = q.branch[i]; counter = q.counter[i];
+        d3 w = mk(q.wx[i], q.wy[i], q.wz[i]);
+        d3 clear = ld3(p.d.clear_color);
+        d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
+        d3 inv_dir = -d;
+        Hit h;
+        prim_full(s, (uint32_t)q.hit_prim[i], o, d, h);
+        const rtx_material& m = s.materials[s.prim_material[h.prim]];
+        bool entering = is_entering(h.normal, inv_dir);
+        d3 local;
+        if (p.d.flags & RTX_FLAG_NO_LIGHTING) {
+            local = material_color(s, m, h.u, h.v);
+        } else {
+            d3 direct = mk(0, 0, 0);
+            uint32_t k = shadow_base[i];
+            for (uint32_t li = 0; li < s.n_lights; ++li) {
+                const rtx_light& l = s.lights[li];
+                uint32_t samples = l.multisample ? p.d.light_multisample_n * p.d.light_multisample_n : 1u;
+                for (uint32_t sm = 0; sm < samples; ++sm, ++k) {
+                    Ray lr;
+                    lr.o = mk(sq.ox[k], sq.oy[k], sq.oz[k]);
+                    lr.d = mk(sq.dx[k], sq.dy[k], sq.dz[k]);
+                    double ldist = light_distance(l, lr);
+                    if (ldist < sq.hit_depth[k]) {
+                        double att = light_attenuation(l, ldist, p.d.attenuation);
+                        direct = direct + lighting(s, inv_dir, lr.d, h.normal, h.u, h.v, att, m, ld3(l.color));
+                    }
+                }
+                direct = direct / (double)samples;          // inside the light loop (:498)
+            }
+            local = direct;
+        }
+        double trans = sample_scalar(s, m.transparency_fn, m.transparency, h.u, h.v);
+        ni = sample_scalar(s, m.ni_fn, m.ni, h.u, h.v);
+        double wtrans = 1.0 - (1.0 - trans);
+        bool refract = fabs(trans - 0.0) >= kEps;           // epsilonNotEqual (:535)
+        if (refract) {
+            d3 dir = refraction_ray(normalize3(h.normal), normalize3(d), ni, entering);
+            d3 pos = h.position + ((h.normal * (entering ? -1.0 : 1.0)) * p.d.bias);
+            child_t = make_ray(pos, dir);
+            wt = w * wtrans;
+            if (layer + 1 > p.d.max_depth) sample_add(sample, slot, wt * clear);    // :456-460
+            else spawn_t = true;
+        } else {
+            sample_add(sample, slot, w * (clear * wtrans));  // transparentRayResult stays clearColor (:532)
+        }
+        double wl = 1.0 - trans;
+        if (p.d.flags & RTX_FLAG_WHITTED_REFLECT) {
+            double smooth = sample_scalar(s, m.smoothness_fn, m.smoothness, h.u, h.v);
+            if (smooth != 0.0) {
+                child_r = make_ray(h.position + (h.normal * p.d.bias), mirror_direction(d, h.normal));
+                wr = w * (smooth * wl);
+                if (layer + 1 > p.d.max_depth) sample_add(sample, slot, wr * clear);
+                else spawn_r = true;
+                wl = wl * (1.0 - smooth);
+            }
+        }
+        sample_add(sample, slot, w * (local * wl));
+    }
+    uint32_t jt = wave_reserve(spawn_t, next_count);
+    if (spawn_t && jt < p.queue_cap) push_ray(next, jt, child_t, wt, ni, slot, layer + 1, branch, counter);
+    uint32_t jr = wave_reserve(spawn_r, next_count);
+    if (spawn_r && jr < p.queue_cap) push_ray(next, jr, child_r, wr, ni, slot, layer + 1, branch | (1u << (layer & 31u)), 0u);
+}
+
+// drawBuffer[x + y*frameX] += colorAcum / double(n*n)  (Raytracer.cpp:705-710): the
+// sub-samples are summed in the reference's order (sx outer, sy inner), the quotient
+// is rounded to float and added in FP32.
+__global__ void __launch_bounds__(kBlock)
+k_resolve(RenderParams p, const double* __restrict__ sample, float* accum)
+{
+    uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= p.chunk_pixels) return;
+    uint32_t x, y;
+    if (!pixel_of(p, p.chunk_t0 + k, x, y)) return;
+    uint32_t nn = p.n * p.n;
+    d3 acum = mk(0, 0, 0);
+    for (uint32_t sub = 0; sub < nn; ++sub) {
+        const double* sp = sample + 3 * ((size_t)k * nn + sub);
+        acum = acum + mk(sp[0], sp[1], sp[2]);
+    }
+    d3 px = acum / (double)nn;
+    size_t at = 3 * ((size_t)(x - p.d.tile_x0) + (size_t)(y - p.d.tile_y0) * p.d.tile_w);
+    accum[at + 0] += (float)px.x;
+    accum[at + 1] += (float)px.y;
+    accum[at + 2] += (float)px.z;
+}
+
+}  // namespace rtx

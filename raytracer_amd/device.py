@@ -1,0 +1,141 @@
+"""Python face of the C ABI in include/rtx.h (raytracer_amd/csrc/librtx_hip.so).
+
+This module only marshals arguments; every computation happens in the HIP
+library.  If the library is missing or no MI355X is usable the calls raise --
+there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(_HERE, "csrc", "librtx_hip.so")
+_lib = None
+
+PD = C.POINTER(C.c_double)
+
+# every symbol include/rtx.h declares
+EXPORTS = ["rtx_init", "rtx_device_count", "rtx_scene_create", "rtx_scene_set_stream", "rtx_scene_destroy",
+           "rtx_trace_closest", "rtx_render", "rtx_render_device", "rtx_uniform", "rtx_last_error"]
+
+
+class RtxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"rtx error {code}: {message}")
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(HIP_LIB):
+        raise RuntimeError(f"{HIP_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(HIP_LIB)
+    L.rtx_init.argtypes = [C.c_int]
+    L.rtx_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_void_p)]
+    L.rtx_scene_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.rtx_scene_destroy.argtypes = [C.c_void_p]
+    L.rtx_scene_destroy.restype = None
+    L.rtx_trace_closest.argtypes = [
+        C.c_void_p, PD, PD, C.c_size_t, C.c_uint32, C.POINTER(C.c_int32), PD, PD, PD, PD, PD,
+        C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
+    L.rtx_render.argtypes = [C.c_void_p, C.POINTER(abi.RenderDesc), C.POINTER(C.c_float), C.POINTER(abi.Stats)]
+    L.rtx_render_device.argtypes = [C.c_void_p, C.POINTER(abi.RenderDesc), C.c_void_p, C.POINTER(abi.Stats)]
+    L.rtx_uniform.restype = C.c_double
+    L.rtx_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.rtx_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != abi.RTX_OK:
+        raise RtxError(rc, lib().rtx_last_error().decode())
+
+
+def init(device=-1):
+    _check(lib().rtx_init(device))
+
+
+def device_count():
+    return lib().rtx_device_count()
+
+
+class DeviceScene:
+    """One frame's scene resident in HBM (rtx_scene_create .. rtx_scene_destroy)."""
+
+    def __init__(self, desc, stream=None):
+        self._L = lib()
+        h = C.c_void_p()
+        _check(self._L.rtx_scene_create(C.byref(desc), C.byref(h)))
+        self._h = h
+        if stream is not None:
+            _check(self._L.rtx_scene_set_stream(self._h, C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rtx_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def trace_closest(self, origin, direction, flags=0, leaf_seq_cap=0, want_counters=False):
+        """Batched shootRay.  Returns a dict of numpy arrays (same keys as the oracle binding)."""
+        origin = np.ascontiguousarray(origin, dtype=np.float64)
+        direction = np.ascontiguousarray(direction, dtype=np.float64)
+        n = origin.size // 3
+        assert direction.size == n * 3
+        prim = np.zeros(n, np.int32)
+        depth = np.zeros(n)
+        position = np.zeros((n, 3))
+        normal = np.zeros((n, 3))
+        uv = np.zeros((n, 2))
+        bary = np.zeros((n, 3))
+        leaf_count = np.zeros(n, np.uint32)
+        leaf_hash = np.zeros(n, np.uint64)
+        leaf_seq = np.full((n, max(leaf_seq_cap, 1)), 0xFFFFFFFF, np.uint32)
+        counters = np.zeros((n, 6), np.uint32)
+        p = lambda a: a.ctypes.data_as(PD)
+        _check(self._L.rtx_trace_closest(
+            self._h, p(origin), p(direction), n, flags, prim.ctypes.data_as(C.POINTER(C.c_int32)), p(depth),
+            p(position), p(normal), p(uv), p(bary), leaf_count.ctypes.data_as(C.POINTER(C.c_uint32)),
+            leaf_hash.ctypes.data_as(C.POINTER(C.c_uint64)),
+            leaf_seq.ctypes.data_as(C.POINTER(C.c_uint32)) if leaf_seq_cap else None, leaf_seq_cap,
+            counters.ctypes.data_as(C.POINTER(C.c_uint32)) if want_counters else None))
+        return dict(prim=prim, depth=depth, position=position, normal=normal, uv=uv, bary=bary,
+                    leaf_count=leaf_count, leaf_hash=leaf_hash, leaf_seq=leaf_seq, counters=counters)
+
+    def render(self, rd, accum=None, want_stats=True):
+        """rtx_render on a host buffer.  Returns (accum float32 [tile_h, tile_w, 3], Stats)."""
+        if accum is None:
+            accum = np.zeros((rd.tile_h, rd.tile_w, 3), np.float32)
+        assert accum.dtype == np.float32 and accum.size == rd.tile_w * rd.tile_h * 3 and accum.flags.c_contiguous
+        stats = abi.Stats()
+        _check(self._L.rtx_render(self._h, C.byref(rd), accum.ctypes.data_as(C.POINTER(C.c_float)),
+                                  C.byref(stats) if want_stats else None))
+        return accum, stats
+
+    def render_device(self, rd, accum_ptr, want_stats=True):
+        """rtx_render_device on device memory (e.g. a torch tensor's data_ptr())."""
+        stats = abi.Stats()
+        _check(self._L.rtx_render_device(self._h, C.byref(rd), C.c_void_p(accum_ptr),
+                                         C.byref(stats) if want_stats else None))
+        return stats
+
+
+def uniform(seed, frame, pixel, sample, branch, draw):
+    return lib().rtx_uniform(seed, frame, pixel, sample, branch, draw)

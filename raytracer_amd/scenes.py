@@ -1,0 +1,209 @@
+"""Scene recipes, built through the host scene API.
+
+`live_scene` is the scene hard-coded in the reference's main()
+(Raytracer/Raytracer.cpp:458-527).  The others are the benchmark
+configurations: the reference ships no scene files, so they are assembled from
+the pieces its three main() variants show (Raytracer-Noah-Desktop.cpp:665-754,
+Raytracer-noah-laptop.cpp:584-611) with seeded procedural geometry standing in
+for the FBX meshes (which need the absent assimp to import).
+"""
+import numpy as np
+
+from . import abi
+from .host import HostScene, make_camera
+
+
+def render_desc(width, height, integrator=abi.INTEGRATOR_WHITTED, camera=None, n=1, light_n=1, max_depth=3,
+                bias=1e-3, clear=(0.0, 0.0, 0.0), flags=0, passes=1, first_pass=0, seed=0, frame=0, tile=None):
+    rd = abi.RenderDesc()
+    rd.integrator = integrator
+    rd.flags = flags
+    rd.width, rd.height = width, height
+    x0, y0, w, h = tile if tile is not None else (0, 0, width, height)
+    rd.tile_x0, rd.tile_y0, rd.tile_w, rd.tile_h = x0, y0, w, h
+    rd.pixel_multisample_n = n
+    rd.light_multisample_n = light_n
+    rd.max_depth = max_depth
+    rd.first_pass, rd.passes = first_pass, passes
+    rd.frame, rd.seed = frame, seed
+    rd.bias = bias
+    rd.clear_color[:] = clear
+    rd.attenuation[:] = (1.0, 0.09, 0.032)      # LIGHT_CONTSTANT/LINEAR/QUADRATIC, Desktop :78-80
+    if camera is not None:
+        rd.camera = camera
+    return rd
+
+
+def _floor(scene, material, half=1000.0, y=0.0, order=("acb", "adc")):
+    """Two floor triangles with uv 0..1 over the quad (Raytracer.cpp:475-500)."""
+    v = {"a": ((-half, y, -half), (0.0, 0.0)), "b": ((half, y, -half), (1.0, 0.0)),
+         "c": ((half, y, half), (1.0, 1.0)), "d": ((-half, y, half), (0.0, 1.0))}
+    pos, nrm, uv = [], [], []
+    for tri in order:
+        for k in tri:
+            pos.append(v[k][0])
+            nrm.append((0.0, 1.0, 0.0))
+            uv.append(v[k][1])
+    scene.triangles(np.array(pos), np.array(nrm), np.array(uv), material)
+
+
+def live_scene():
+    """The scene of Raytracer.cpp:458-527: 2 floor triangles, mirror sphere, 4 glass
+    spheres, 3 emissive spheres on circle0/1/2.  Camera of :642-660."""
+    s = HostScene()
+    white = s.material("PlainWhiteTees", color=(1.0, 1.0, 1.0))
+    glass = s.material("Glass")
+    mirror = s.material("Mirror")
+    _floor(s, white)
+    s.sphere((0.0, 2.5, 0.0), 5.0, mirror)
+    for c in [(-7.0, 1.5, 7.0), (-7.0, 1.5, -7.0), (7.0, 1.5, 7.0), (7.0, 1.5, -7.0)]:
+        s.sphere(c, 1.5, glass)
+    for k, e in enumerate([(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)]):
+        s.sphere((0.0, 0.0, 0.0), 1.0, s.material("PlainWhiteTees", emission=e), motion=f"circle{k}")
+    cam = make_camera((0.0, 35.0, 50.0), (0.0, 0.0, 0.0))
+    return s, cam
+
+
+def whitted_scene():
+    """Config 1: glass + mirror sphere over a red/yellow checker floor, one PointLight."""
+    s = HostScene()
+    checkers = s.material("PlainWhiteTees", color_sampler=abi.SAMPLER_RY_CHECKERS)
+    glass = s.material("Glass")
+    mirror = s.material("Mirror")
+    _floor(s, checkers)
+    s.sphere((-2.2, 2.0, 0.0), 2.0, glass)
+    s.sphere((2.4, 1.6, -2.5), 1.6, mirror)
+    s.point_light((5.0, 5.0, 5.0), (1.0, 1.0, 1.0))
+    cam = make_camera((0.0, 3.0, 9.0), (0.0, 1.2, 0.0))
+    return s, cam
+
+
+def bumpy_sphere(slices=246, stacks=123, radius=3.0, center=(0.0, 0.5, 0.0), bump=0.08, seed=12345):
+    """Seeded procedural triangle soup: a UV sphere whose radius is modulated by a few
+    random sinusoids.  slices*(stacks-1)*2 triangles (60 024 by default), smooth
+    per-vertex normals, uv = (longitude, latitude)."""
+    rng = np.random.default_rng(seed)
+    k = rng.integers(2, 9, size=(6, 2)).astype(np.float64)
+    ph = rng.uniform(0.0, 2 * np.pi, size=6)
+    amp = rng.uniform(0.3, 1.0, size=6)
+    amp /= amp.sum()
+    i = np.arange(slices + 1)
+    j = np.arange(stacks + 1)
+    theta = 2 * np.pi * (i % slices) / slices                # longitude
+    phi = np.pi * j / stacks                                 # colatitude
+    T, P = np.meshgrid(theta, phi, indexing="ij")
+    r = np.ones_like(T)
+    for q in range(6):
+        r += bump * amp[q] * np.sin(k[q, 0] * T + ph[q]) * np.sin(k[q, 1] * P)
+    d = np.stack([np.sin(P) * np.cos(T), np.cos(P), np.sin(P) * np.sin(T)], axis=-1)
+    pts = np.asarray(center) + radius * r[..., None] * d
+    nrm = d.copy()
+    U, Vv = np.meshgrid(i / slices, j / stacks, indexing="ij")
+    uvs = np.stack([U, 1.0 - Vv], axis=-1)
+    pos, nn, uu = [], [], []
+
+    def quad_tris(i0, j0):
+        a, b, c, dd = (i0, j0), (i0 + 1, j0), (i0 + 1, j0 + 1), (i0, j0 + 1)
+        out = []
+        if j0 > 0:
+            out.append((a, b, c))
+        if j0 < stacks - 1:
+            out.append((a, c, dd))
+        return out
+
+    idx = []
+    for i0 in range(slices):
+        for j0 in range(stacks):
+            idx.extend(quad_tris(i0, j0))
+    idx = np.array(idx)                                       # [n,3,2]
+    ii, jj = idx[..., 0], idx[..., 1]
+    pos = pts[ii, jj]                                         # [n,3,3]
+    nn = nrm[ii, jj]
+    uu = uvs[ii, jj]
+    # outward-facing winding: the reference culls triangles whose determinant is negative
+    e1 = pos[:, 1] - pos[:, 0]
+    e2 = pos[:, 2] - pos[:, 0]
+    face = np.cross(e1, e2)
+    flip = np.einsum("ij,ij->i", face, nn[:, 0] + nn[:, 1] + nn[:, 2]) < 0
+    pos[flip] = pos[flip][:, [0, 2, 1]]
+    nn[flip] = nn[flip][:, [0, 2, 1]]
+    uu[flip] = uu[flip][:, [0, 2, 1]]
+    return pos.reshape(-1, 9), nn.reshape(-1, 9), uu.reshape(-1, 6)
+
+
+def checker_texture(size=256, cells=8, seed=7):
+    """Seeded RGB8 albedo texture (stand-in for the FBX models' albedo maps)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:size, 0:size]
+    cell = ((x * cells // size) + (y * cells // size)) % 2
+    base = np.where(cell[..., None] == 0, np.array([200, 120, 60]), np.array([60, 120, 200]))
+    noise = rng.integers(-20, 21, size=(size, size, 3))
+    return np.clip(base + noise, 0, 255).astype(np.uint8)
+
+
+def mesh_scene(slices=246, stacks=123, t=0.0, ggx=False, square_light=False):
+    """Configs 2 and 4: a triangle mesh + floor.  Config 2: constant white material,
+    DirectionalLight((-1,-1,-1)) (Raytracer-noah-laptop.cpp:608-611), orbit camera
+    eye = (10 sin t, 0.1, 10 cos t) (:672).  Config 4 (ggx=True): smoothness/metalness
+    > 0, albedo texture on the mesh, checker floor and (square_light) a 1x1 SquareLight
+    at (0,10,0) facing down (Raytracer-Noah-Desktop.cpp:754)."""
+    s = HostScene()
+    if ggx:
+        tex = s.texture(checker_texture())
+        mesh_mat = s.material_custom((1.0, 1.0, 1.0), ns=100.0, ni=1.0, transparency=0.0, metalness=0.5,
+                                     smoothness=0.5, samplers={"color": (abi.SAMPLER_TEXTURE_VEC3, tex)})
+        floor_mat = s.material("PlainWhiteTees", color_sampler=abi.SAMPLER_RY_CHECKERS)
+    else:
+        mesh_mat = s.material("PlainWhiteTees")
+        floor_mat = s.material("PlainWhiteTees", color=(0.8, 0.8, 0.8))
+    pos, nrm, uv = bumpy_sphere(slices, stacks)
+    s.triangles(pos, nrm, uv, mesh_mat)
+    _floor(s, floor_mat, half=20.0, y=-3.0)
+    if square_light:
+        s.square_light((0.0, 10.0, 0.0), (0.0, -1.0, 0.0), 1.0, 1.0)
+    else:
+        s.directional_light((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0))
+    cam = make_camera((10.0 * np.sin(t), 0.1, 10.0 * np.cos(t)), (0.0, 0.0, 0.0))
+    return s, cam
+
+
+def lens_scene():
+    """Config 3: the Whitted scene plus a Biconvex lens, a mirror sphere and an emissive
+    sphere as the light (path-tracing semantics, Raytracer.cpp:525-527)."""
+    s = HostScene()
+    checkers = s.material("PlainWhiteTees", color_sampler=abi.SAMPLER_RY_CHECKERS)
+    glass = s.material("Glass")
+    mirror = s.material("Mirror")
+    copper = s.material("Copper")
+    lamp = s.material("PlainWhiteTees", emission=(6.0, 6.0, 6.0))
+    _floor(s, checkers)
+    s.sphere((-2.2, 2.0, 0.0), 2.0, glass)
+    s.sphere((2.4, 1.6, -2.5), 1.6, mirror)
+    s.sphere((4.5, 1.0, 2.0), 1.0, copper)
+    s.sphere((0.0, 12.0, 3.0), 4.0, lamp)
+    s.biconvex((0.0, 2.0, 4.0), (0.0, 0.0, 1.0), 3.0, 50.0)
+    cam = make_camera((0.0, 3.0, 9.0), (0.0, 1.2, 0.0))
+    return s, cam
+
+
+def animated_scene(copies=1, slices=246, stacks=123):
+    """Config 5: `copies` bumpy spheres (about 60k triangles each) + floor + three emissive
+    spheres on circle0/1/2 (Animatable.cpp:22-35); the caller picks t = frame/30."""
+    s = HostScene()
+    floor_mat = s.material("PlainWhiteTees", color_sampler=abi.SAMPLER_RY_CHECKERS)
+    _floor(s, floor_mat, half=1000.0, y=-3.0)
+    side = int(np.ceil(np.sqrt(copies)))
+    for c in range(copies):
+        gx, gz = c % side, c // side
+        mat = s.material_custom((0.9, 0.9, 0.9), metalness=0.3 + 0.4 * ((c * 7) % 5) / 5.0, smoothness=0.4)
+        center = ((gx - (side - 1) / 2) * 7.0, 0.5, (gz - (side - 1) / 2) * 7.0)
+        rng_seed = 12345 + c
+        pos, nrm, uv = bumpy_sphere(slices, stacks, center=center, seed=rng_seed)
+        s.triangles(pos, nrm, uv, mat)
+    for k, e in enumerate([(8.0, 2.0, 2.0), (2.0, 8.0, 2.0), (2.0, 2.0, 8.0)]):
+        s.sphere((0.0, 0.0, 0.0), 1.0, s.material("PlainWhiteTees", emission=e), motion=f"circle{k}")
+    return s
+
+
+def orbit_camera(t, radius=10.0, height=0.1):
+    return make_camera((radius * np.sin(t), height, radius * np.cos(t)), (0.0, 0.0, 0.0))
