@@ -184,8 +184,14 @@ enum {
                                            as in pathTrace case 2 (Raytracer.cpp:284-285)
                                            blended by smoothness                           */
     RTX_FLAG_COUNTERS        = 1u << 4, /* fill the traversal work counters of rtx_stats   */
-    RTX_FLAG_PER_LANE        = 1u << 5, /* force the one-ray-per-lane traversal kernel     */
-    RTX_FLAG_PACKET          = 1u << 6  /* force the wave-packet traversal kernel          */
+    RTX_FLAG_REFERENCE_ORDER = 1u << 5, /* walk the KD tree node for node as traverseKDTree
+                                           does (KDTree.cpp:158-204).  Without it the
+                                           render path walks the same tree but skips
+                                           nodes that provably cannot change the closest
+                                           hit and stops shadow rays at the first occluder;
+                                           hit ids, depths and images are identical, only
+                                           the work (and the counters) shrink             */
+    RTX_FLAG_STAGE_TIMES     = 1u << 7  /* fill the per-stage ms_* fields of rtx_stats     */
 };
 
 /* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;
@@ -215,14 +221,17 @@ typedef struct rtx_stats {
     uint64_t rays_primary;
     uint64_t rays_secondary;
     uint64_t rays_shadow;
-    /* per-ray work counters summed over all queries; filled with RTX_FLAG_COUNTERS */
+    /* per-ray work counters summed over all queries; filled with RTX_FLAG_COUNTERS.
+       With RTX_FLAG_REFERENCE_ORDER they are the reference's own work. */
     uint64_t branch_visits;         /* KDBranch slab tests                       */
     uint64_t leaf_visits;
     uint64_t aabb_tests;            /* Shape::rayAABB calls                      */
     uint64_t triangle_tests;        /* Triangle::rayHit calls                    */
     uint64_t sphere_tests;          /* Sphere::rayHit calls (2 per lens)         */
     uint64_t hits_accepted;         /* closer-hit replacements                   */
-    /* device time per stage in milliseconds (HIP events on the library stream) */
+    uint64_t content_tests;         /* content-box tests of the culled walk      */
+    /* device time per stage in milliseconds (HIP events on the library stream);
+       ms_total always, the per-stage sums with RTX_FLAG_STAGE_TIMES */
     double ms_generate;
     double ms_traverse;
     double ms_shade;
@@ -260,7 +269,7 @@ void rtx_scene_destroy(rtx_scene* scene);
  *   leaf_count[i]  number of KDLeaf visits      leaf_hash[i]  FNV-1a-64 over the leaf ids
  *   leaf_seq       [n*leaf_seq_cap] first leaf ids visited, rest untouched
  *   counters       [n*6] branch, leaf, aabb, triangle, sphere, accepted per ray
- * flags: RTX_FLAG_LINEAR_SCAN, RTX_FLAG_PER_LANE, RTX_FLAG_PACKET.
+ * flags: RTX_FLAG_LINEAR_SCAN.  This entry point always walks in the reference's order.
  */
 int rtx_trace_closest(rtx_scene* scene, const double* origin, const double* direction, size_t n,
                       uint32_t flags, int32_t* prim, double* depth, double* position,
@@ -275,9 +284,9 @@ int rtx_trace_closest(rtx_scene* scene, const double* origin, const double* dire
  * reference's drawBuffer: float RGB, tile_w*tile_h*3, row 0 = bottom row; each
  * pass performs accum[p] += float(colorAcum / (n*n)) in pass order (FP32, as
  * Raytracer.hpp:77-78).  The caller initialises it (clearBuffers, :53-58).
- * rtx_render takes a host buffer; rtx_render_device takes device memory, runs
- * asynchronously on the scene's stream when stats == NULL, and is what a caller
- * with resident buffers (a multi-GPU gather) uses.
+ * rtx_render takes a host buffer; rtx_render_device takes device memory and is
+ * what a caller with resident buffers (a multi-GPU gather) uses.  Both return
+ * after the work has completed on the scene's stream.
  */
 int rtx_render(rtx_scene* scene, const rtx_render_desc* desc, float* accum, rtx_stats* stats);
 int rtx_render_device(rtx_scene* scene, const rtx_render_desc* desc, float* accum_device,

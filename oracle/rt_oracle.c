@@ -770,8 +770,7 @@ int orc_render(const rtx_scene_desc* s, const rtx_render_desc* d, float* accum, 
     uint64_t c_branch = 0, c_leaf = 0, c_aabb = 0, c_tri = 0, c_sph = 0, c_acc = 0;
     int used = 1;
 #ifdef _OPENMP
-    if (threads > 0) omp_set_num_threads(threads);
-    else omp_set_num_threads(omp_get_num_procs());
+    if (threads > 0) omp_set_num_threads(threads);     /* otherwise OMP_NUM_THREADS / the OpenMP default */
 #endif
     for (uint32_t pass = d->first_pass; pass < d->first_pass + d->passes; ++pass) {
 #pragma omp parallel reduction(+ : t_prim, t_sec, t_shadow, c_branch, c_leaf, c_aabb, c_tri, c_sph, c_acc)

@@ -31,7 +31,7 @@ int orc_trace_closest(const rtx_scene_desc* s, const double* origin, const doubl
                       uint32_t* counters);
 
 /* per-pixel lambda + integrator; same contract as rtx_render.  threads <= 0
- * uses every core OpenMP offers; the number used is returned in *threads_used
+ * keeps OpenMP's default (OMP_NUM_THREADS); the number used is returned in *threads_used
  * (may be NULL).  rgb64, when not NULL, receives the FP64 colorAcum/(n*n) of the
  * LAST pass per pixel (tile_w*tile_h*3) so tests can compare before FP32 rounding. */
 int orc_render(const rtx_scene_desc* s, const rtx_render_desc* d, float* accum, double* rgb64,

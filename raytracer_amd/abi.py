@@ -30,8 +30,8 @@ FLAG_BASIC = 1 << 1
 FLAG_NO_LIGHTING = 1 << 2
 FLAG_WHITTED_REFLECT = 1 << 3
 FLAG_COUNTERS = 1 << 4
-FLAG_PER_LANE = 1 << 5
-FLAG_PACKET = 1 << 6
+FLAG_REFERENCE_ORDER = 1 << 5
+FLAG_STAGE_TIMES = 1 << 7
 
 # motion functions of the host API (Animatable.cpp:5-35), by rth_add_sphere code
 MOTION = {"noMovement": 0, "oscilateX": 1, "oscilateY": 2, "rotateY": 3,
@@ -118,6 +118,7 @@ class Stats(C.Structure):
         ("rays_primary", C.c_uint64), ("rays_secondary", C.c_uint64), ("rays_shadow", C.c_uint64),
         ("branch_visits", C.c_uint64), ("leaf_visits", C.c_uint64), ("aabb_tests", C.c_uint64),
         ("triangle_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("hits_accepted", C.c_uint64),
+        ("content_tests", C.c_uint64),
         ("ms_generate", C.c_double), ("ms_traverse", C.c_double), ("ms_shade", C.c_double),
         ("ms_shadow", C.c_double), ("ms_resolve", C.c_double), ("ms_total", C.c_double),
         ("traverse_launches", C.c_uint32), ("max_queue", C.c_uint32),
@@ -141,6 +142,7 @@ def algorithmic_bytes(stats):
     of ray in / hit out.
     """
     rays = stats.rays_primary + stats.rays_secondary + stats.rays_shadow
-    return (72 * stats.branch_visits + 8 * stats.leaf_visits + 52 * stats.aabb_tests
+    # the culled walk additionally reads one 48 B content box per node it considers
+    return (48 * stats.content_tests + 72 * stats.branch_visits + 8 * stats.leaf_visits + 52 * stats.aabb_tests
             + 72 * stats.triangle_tests + 32 * stats.sphere_tests + 124 * stats.hits_accepted
             + 88 * rays)

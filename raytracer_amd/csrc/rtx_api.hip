@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -117,9 +119,9 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap)
     Workspace& w = sc->ws;
     if (!w.counts) {
         HIP_TRY(hipMalloc(&w.counts, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&w.work, 6 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&w.work, 8 * sizeof(unsigned long long)));
         HIP_TRY(hipHostMalloc(&w.host_counts, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc(&w.host_work, 6 * sizeof(unsigned long long)));
+        HIP_TRY(hipHostMalloc(&w.host_work, 8 * sizeof(unsigned long long)));
     }
     if (cap > w.capacity) {
         if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.capacity = 0; }
@@ -142,11 +144,12 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap)
     if (shadow_cap > w.shadow_capacity) {
         if (w.shadow_base_mem) { HIP_TRY(hipFree(w.shadow_base_mem)); w.shadow_base_mem = nullptr; w.shadow_capacity = 0; }
         auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
-        HIP_TRY(hipMalloc(&w.shadow_base_mem, 7 * al(shadow_cap * 8)));
+        HIP_TRY(hipMalloc(&w.shadow_base_mem, 8 * al(shadow_cap * 8)));
         char* p = w.shadow_base_mem;
         ShadowQueue& s = w.sq;
         s.ox = carve<double>(p, shadow_cap); s.oy = carve<double>(p, shadow_cap); s.oz = carve<double>(p, shadow_cap);
         s.dx = carve<double>(p, shadow_cap); s.dy = carve<double>(p, shadow_cap); s.dz = carve<double>(p, shadow_cap);
+        s.limit = carve<double>(p, shadow_cap);
         s.hit_depth = carve<double>(p, shadow_cap);
         w.shadow_capacity = shadow_cap;
     }
@@ -223,24 +226,43 @@ int validate_scene(const rtx_scene_desc* s, uint32_t* kd_depth)
 
 inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
+// Device time per stage: event pairs are recorded on the library stream without
+// waiting and read back once the stream has drained.
 struct StageTimer {
     bool on;
     hipStream_t stream;
-    hipEvent_t a = nullptr, b = nullptr;
-    StageTimer(bool on, hipStream_t s) : on(on), stream(s)
+    struct Span { hipEvent_t a, b; double* acc; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t cur = nullptr;
+    StageTimer(bool on, hipStream_t s) : on(on), stream(s) {}
+    ~StageTimer()
     {
-        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+        for (Span& sp : spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+        if (cur) (void)hipEventDestroy(cur);
     }
-    ~StageTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-    void begin() { if (on) (void)hipEventRecord(a, stream); }
-    void end(double* acc)
+    void begin()
     {
         if (!on) return;
+        (void)hipEventCreate(&cur);
+        (void)hipEventRecord(cur, stream);
+    }
+    void end(double* acc)
+    {
+        if (!on || !cur) return;
+        hipEvent_t b = nullptr;
+        (void)hipEventCreate(&b);
         (void)hipEventRecord(b, stream);
-        (void)hipEventSynchronize(b);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, a, b);
-        *acc += ms;
+        spans.push_back(Span{cur, b, acc});
+        cur = nullptr;
+    }
+    // call after the stream has been synchronised
+    void collect()
+    {
+        for (Span& sp : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) *sp.acc += ms;
+        }
     }
 };
 
@@ -316,10 +338,51 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
         info[i] = (uint32_t)s->prim_type[i] | (s->prim_index[i] << 2);
     }
 
+    // content boxes for the culled walk: per leaf the union of its shape boxes, per branch
+    // the union of its children's (an empty leaf gets an inverted box that no ray hits)
+    std::vector<PrimBox> leaf_cbox(s->n_leaves), branch_cbox(s->n_branches);
+    const double big = std::numeric_limits<double>::max();
+    auto grow = [](PrimBox& a, const PrimBox& b) {
+        for (int k = 0; k < 3; ++k) { a.bmin[k] = std::min(a.bmin[k], b.bmin[k]); a.bmax[k] = std::max(a.bmax[k], b.bmax[k]); }
+    };
+    for (uint32_t i = 0; i < s->n_leaves; ++i) {
+        PrimBox c;
+        for (int k = 0; k < 3; ++k) { c.bmin[k] = big; c.bmax[k] = -big; }
+        for (uint32_t r = 0; r < s->leaf_count[i]; ++r) grow(c, boxes[s->leaf_refs[s->leaf_first[i] + r]]);
+        leaf_cbox[i] = c;
+    }
+    {
+        // children before parents: explicit post-order walk (the tree was validated above)
+        std::vector<std::pair<int32_t, int>> st;
+        if (s->kd_root >= 0) st.push_back({s->kd_root, 0});
+        while (!st.empty()) {
+            auto [node, phase] = st.back();
+            if (phase == 0) {
+                st.back().second = 1;
+                int32_t l = s->branch_lesser[node], g = s->branch_greater[node];
+                if (l >= 0) st.push_back({l, 0});
+                if (g >= 0) st.push_back({g, 0});
+            } else {
+                st.pop_back();
+                PrimBox c;
+                for (int k = 0; k < 3; ++k) { c.bmin[k] = big; c.bmax[k] = -big; }
+                for (int32_t ch : {s->branch_lesser[node], s->branch_greater[node]})
+                    grow(c, ch >= 0 ? branch_cbox[ch] : leaf_cbox[(uint32_t)~ch]);
+                branch_cbox[node] = c;
+            }
+        }
+    }
+    double scale = 0.0;
+    for (const PrimBox& b : boxes)
+        for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(b.bmin[k]), std::fabs(b.bmax[k])));
+    d.scene_scale = scale;
+
     DeviceBuffers& B = sc->buffers;
     hipError_t e = hipSuccess;
     auto up = [&](auto host, size_t count, auto out_ptr) { if (e == hipSuccess) e = B.upload(host, count, out_ptr); };
     up(branches.data(), branches.size(), &d.branches);
+    up(branch_cbox.data(), branch_cbox.size(), &d.branch_cbox);
+    up(leaf_cbox.data(), leaf_cbox.size(), &d.leaf_cbox);
     up(leaves.data(), leaves.size(), &d.leaves);
     up(s->leaf_refs, (size_t)s->n_leaf_refs, &d.leaf_refs);
     up(boxes.data(), boxes.size(), &d.prim_box);
@@ -406,19 +469,25 @@ int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* directi
     return RTX_OK;
 }
 
+// limit == nullptr: closest hit; otherwise any hit with depth <= limit[i] (shadow rays)
 static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const double* oz, const double* dx,
-                        const double* dy, const double* dz, uint32_t n, uint32_t flags, int32_t* hit_prim,
-                        double* hit_depth, bool count)
+                        const double* dy, const double* dz, const double* limit, uint32_t n, uint32_t flags,
+                        int32_t* hit_prim, double* hit_depth, bool count)
 {
     uint32_t linear = (flags & RTX_FLAG_LINEAR_SCAN) ? 1u : 0u;
+    int mode = (flags & (RTX_FLAG_REFERENCE_ORDER | RTX_FLAG_LINEAR_SCAN)) ? 0 : (limit ? 2 : 1);
     Counters g;
     g.c = count ? sc->ws.work : nullptr;
-    if (count)
-        hipLaunchKernelGGL(k_trace_pool<true>, grid_for(n), dim3(kBlock), 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, n,
-                           linear, hit_prim, hit_depth, g);
-    else
-        hipLaunchKernelGGL(k_trace_pool<false>, grid_for(n), dim3(kBlock), 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, n,
-                           linear, hit_prim, hit_depth, g);
+    dim3 grid = grid_for(n), block(kBlock);
+#define RTX_LAUNCH_TRACE(COUNT, MODE)                                                                                  \
+    hipLaunchKernelGGL((k_trace_pool<COUNT, MODE>), grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
+                       linear, hit_prim, hit_depth, g)
+    if (count) {
+        if (mode == 0) RTX_LAUNCH_TRACE(true, 0); else if (mode == 1) RTX_LAUNCH_TRACE(true, 1); else RTX_LAUNCH_TRACE(true, 2);
+    } else {
+        if (mode == 0) RTX_LAUNCH_TRACE(false, 0); else if (mode == 1) RTX_LAUNCH_TRACE(false, 1); else RTX_LAUNCH_TRACE(false, 2);
+    }
+#undef RTX_LAUNCH_TRACE
     HIP_TRY(hipGetLastError());
     return RTX_OK;
 }
@@ -477,10 +546,10 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
 
     rtx_stats local;
     std::memset(&local, 0, sizeof local);
-    StageTimer timer(stats != nullptr, st);
+    StageTimer timer(stats != nullptr && (rd->flags & RTX_FLAG_STAGE_TIMES), st);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, st)); }
-    if (count_work) HIP_TRY(hipMemsetAsync(w.work, 0, 6 * sizeof(unsigned long long), st));
+    if (count_work) HIP_TRY(hipMemsetAsync(w.work, 0, 8 * sizeof(unsigned long long), st));
 
     for (uint32_t pass = rd->first_pass; pass < rd->first_pass + rd->passes; ++pass) {
         p.pass = pass;
@@ -506,7 +575,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 local.max_queue = std::max(local.max_queue, count);
                 if (level == 0) local.rays_primary += count; else local.rays_secondary += count;
                 timer.begin();
-                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, count, rd->flags, q.hit_prim, q.hit_depth, count_work);
+                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, count, rd->flags, q.hit_prim, q.hit_depth, count_work);
                 if (rc != RTX_OK) return rc;
                 timer.end(&local.ms_traverse);
                 local.traverse_launches++;
@@ -529,7 +598,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                     if (nshadow > 0) {
                         local.rays_shadow += nshadow;
                         timer.begin();
-                        rc = launch_trace(sc, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, nshadow, rd->flags, nullptr,
+                        rc = launch_trace(sc, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, w.sq.limit, nshadow, rd->flags, nullptr,
                                           w.sq.hit_depth, count_work);
                         if (rc != RTX_OK) return rc;
                         timer.end(&local.ms_shadow);
@@ -553,7 +622,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         }
     }
     if (count_work) {
-        HIP_TRY(hipMemcpyAsync(w.host_work, w.work, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(w.host_work, w.work, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     }
     if (stats) HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -561,10 +630,12 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         local.ms_total = ms;
+        timer.collect();
         (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
         if (count_work) {
             local.branch_visits = w.host_work[0]; local.leaf_visits = w.host_work[1]; local.aabb_tests = w.host_work[2];
             local.triangle_tests = w.host_work[3]; local.sphere_tests = w.host_work[4]; local.hits_accepted = w.host_work[5];
+            local.content_tests = w.host_work[6];
         }
         *stats = local;
     }

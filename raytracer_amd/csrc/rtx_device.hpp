@@ -104,7 +104,10 @@ struct PrimBox { double bmin[3]; double bmax[3]; };   // 48 bytes
 struct DScene {
     int32_t root;
     uint32_t n_branches, n_leaves, n_leaf_refs, n_shapes, n_prims, n_lights, n_materials, n_textures;
+    double scene_scale;             // largest |coordinate| of the scene box
     const Branch* branches;
+    const PrimBox* branch_cbox;     // per branch: union of the shape boxes below it
+    const PrimBox* leaf_cbox;       // per leaf: union of its shape boxes
     const uint2* leaves;            // (first, count)
     const uint32_t* leaf_refs;
     const PrimBox* prim_box;

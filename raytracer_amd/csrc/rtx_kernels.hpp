@@ -33,10 +33,11 @@ struct RayQueue {
 
 struct ShadowQueue {
     double *ox, *oy, *oz, *dx, *dy, *dz;
+    double *limit;                          // light distance: hits beyond it do not matter
     double *hit_depth;
 };
 
-struct Counters { unsigned long long* c; };     // 6 global work counters, or null
+struct Counters { unsigned long long* c; };     // 8 global work counters, or null
 
 struct RenderParams {
     rtx_render_desc d;
@@ -69,6 +70,7 @@ RTX_DEV uint32_t wave_reserve(bool pred, uint32_t* counter, uint32_t per_item = 
 template <bool COUNT>
 struct Work {
     uint32_t branch = 0, leaf = 0, aabb = 0, tri = 0, sph = 0, accepted = 0;
+    uint32_t content = 0;           // content-box tests of the culled walk
     uint32_t leaf_count = 0;
     unsigned long long leaf_hash = 14695981039346656037ull;
 };
@@ -164,12 +166,152 @@ RTX_DEV void trace_lane(const DScene& s, d3 o, d3 d, bool linear, int32_t* stack
     }
 }
 
+// ---- culled traversal: same answer, less work ---------------------------------------------------
+// shootRay's result is the lexicographic minimum of (depth, position in the reference's
+// visit order) over the candidates the reference's walk generates: it replaces the best
+// hit only on a strictly smaller depth (KDTree.cpp:212) and always walks lesser before
+// greater, so leaf-reference index order IS its visit order.  That minimum does not depend
+// on the order in which candidates are examined, and candidates that provably cannot win
+// need not be examined at all.  This walk therefore
+//   * applies the reference's own branch predicate (region slab test + enter/exit against
+//     the split value), so it never enters a subtree the reference would not enter;
+//   * skips a node when the ray misses the node's content box (the union of the shape boxes
+//     below it): the slab arithmetic is monotone in the box for finite 1/direction, so every
+//     shape-box test below would fail as well (Shape.cpp:100-116);
+//   * skips a node when the Euclidean distance from the ray origin to the content box
+//     exceeds the best depth so far by a safety margin: every hit point the reference
+//     computes lies in its shape's box (a convex combination of the vertices, or a point
+//     on the sphere), and depth is its distance from the origin (Triangle.cpp:52-55,
+//     Sphere.cpp:73-77);
+//   * visits the nearer child first so that the bound tightens early;
+//   * in ANYHIT form (shadow rays) stops at the first candidate with depth <= limit,
+//     which decides `lightDistance < depth` (Raytracer-Noah-Desktop.cpp:492) identically.
+// Rays whose 1/direction is not finite (axis-parallel rays: NaNs can reach the slab tests)
+// take the reference-order walk instead.
+RTX_DEV void slab_finite(const PrimBox* __restrict__ b, d3 o, d3 inv, double& tmin, double& tmax)
+{
+    // for non-NaN operands min/max instructions agree with glm's selects up to the sign
+    // of zero, which no comparison below can observe
+    double t0x = (b->bmin[0] - o.x) * inv.x, t1x = (b->bmax[0] - o.x) * inv.x;
+    double t0y = (b->bmin[1] - o.y) * inv.y, t1y = (b->bmax[1] - o.y) * inv.y;
+    double t0z = (b->bmin[2] - o.z) * inv.z, t1z = (b->bmax[2] - o.z) * inv.z;
+    tmin = __builtin_fmax(__builtin_fmin(t0x, t1x), __builtin_fmax(__builtin_fmin(t0y, t1y), __builtin_fmin(t0z, t1z)));
+    tmax = __builtin_fmin(__builtin_fmax(t0x, t1x), __builtin_fmin(__builtin_fmax(t0y, t1y), __builtin_fmax(t0z, t1z)));
+}
+
+RTX_DEV double box_distance2(const PrimBox* __restrict__ b, d3 o)
+{
+    double ex = __builtin_fmax(__builtin_fmax(b->bmin[0] - o.x, o.x - b->bmax[0]), 0.0);
+    double ey = __builtin_fmax(__builtin_fmax(b->bmin[1] - o.y, o.y - b->bmax[1]), 0.0);
+    double ez = __builtin_fmax(__builtin_fmax(b->bmin[2] - o.z, o.z - b->bmax[2]), 0.0);
+    return (ex * ex + ey * ey) + ez * ez;
+}
+
+template <bool COUNT, bool ANYHIT>
+RTX_DEV void trace_lane_culled(const DScene& s, d3 o, d3 d, double limit, int32_t* stack, int32_t& best_prim,
+                               double& best_depth, Work<COUNT>& w)
+{
+    best_prim = -1;
+    best_depth = kInf;
+    uint32_t best_pos = 0xffffffffu;
+    d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    // margin of the distance bound: far above any rounding in the reference's hit points
+    const double abs_margin = 1e-9 * (s.scene_scale + __builtin_fmax(fabs(o.x), __builtin_fmax(fabs(o.y), fabs(o.z))));
+    double bound2 = kInf;
+    if constexpr (ANYHIT) { double bd = limit * (1.0 + 1e-7) + abs_margin; bound2 = bd * bd; }
+    int sp = 0;
+    int32_t node = s.root;
+    for (;;) {
+        const PrimBox* cb = node >= 0 ? s.branch_cbox + node : s.leaf_cbox + (uint32_t)~node;
+        double tmin, tmax;
+        slab_finite(cb, o, inv, tmin, tmax);
+        if constexpr (COUNT) w.content++;
+        if (tmin <= tmax && tmax >= 0.0 && !(box_distance2(cb, o) > bound2)) {
+            if (node >= 0) {
+                const Branch* b = s.branches + node;
+                slab(ld3(b->bmin), ld3(b->bmax), o, inv, tmin, tmax);
+                if constexpr (COUNT) w.branch++;
+                if (tmin < tmax && tmax >= 0.0) {
+                    int axis = b->axis;
+                    double value = b->value;
+                    double oa = pick(o, axis), da = pick(d, axis);
+                    double enter = oa + (da * tmin);
+                    double exit_ = oa + (da * tmax);
+                    int32_t lesser = b->lesser, greater = b->greater;
+                    bool only_lesser, only_greater;
+                    if (enter <= value) { only_lesser = exit_ < value; only_greater = false; }
+                    else { only_greater = exit_ > value; only_lesser = false; }
+                    if (only_greater) node = greater;
+                    else if (only_lesser) node = lesser;
+                    else {
+                        bool lesser_first = da >= 0.0;
+                        stack[sp * kBlock] = lesser_first ? greater : lesser;
+                        ++sp;
+                        node = lesser_first ? lesser : greater;
+                    }
+                    continue;
+                }
+            } else {
+                uint32_t leaf = (uint32_t)~node;
+                if constexpr (COUNT) w.leaf++;
+                uint2 fc = s.leaves[leaf];
+                for (uint32_t k = 0; k < fc.y; ++k) {
+                    uint32_t prim = s.leaf_refs[fc.x + k];
+                    slab_finite(s.prim_box + prim, o, inv, tmin, tmax);
+                    if constexpr (COUNT) w.aabb++;
+                    if (tmin <= tmax && tmax >= 0.0) {
+                        uint32_t info = s.prim_info[prim];
+                        uint32_t type = info & 3u, idx = info >> 2;
+                        double depth = kInf;
+                        uint32_t rp = prim;
+                        bool ok;
+                        if (type == RTX_PRIM_TRIANGLE) {
+                            if constexpr (COUNT) w.tri++;
+                            ok = triangle_depth(s.tri_pos + 9 * (size_t)idx, o, d, depth);
+                        } else if (type == RTX_PRIM_SPHERE) {
+                            if constexpr (COUNT) w.sph++;
+                            ok = sphere_t(ld3(s.sph_center + 3 * (size_t)idx), s.sph_r2[idx], o, d, depth);
+                        } else {
+                            if constexpr (COUNT) w.sph += 2;
+                            ok = biconvex_depth(s, idx, o, d, depth, rp);
+                        }
+                        if (ok) {
+                            if constexpr (ANYHIT) {
+                                if (depth <= limit) { best_depth = depth; best_prim = (int32_t)rp; return; }
+                            } else {
+                                uint32_t pos = fc.x + k;
+                                if (depth < best_depth || (depth == best_depth && pos < best_pos)) {
+                                    if constexpr (COUNT) w.accepted++;
+                                    best_depth = depth; best_prim = (int32_t)rp; best_pos = pos;
+                                    double bd = best_depth * (1.0 + 1e-7) + abs_margin;
+                                    bound2 = bd * bd;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        node = stack[sp * kBlock];
+    }
+    if constexpr (ANYHIT) { best_depth = kInf; best_prim = -1; }     // nothing at or before the light
+}
+
+RTX_DEV bool culling_is_exact(d3 o, d3 d)
+{
+    d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    return isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
+}
+
 RTX_DEV void add_counters(Counters g, const Work<true>& w)
 {
     if (!g.c) return;
     atomicAdd(g.c + 0, (unsigned long long)w.branch); atomicAdd(g.c + 1, (unsigned long long)w.leaf);
     atomicAdd(g.c + 2, (unsigned long long)w.aabb); atomicAdd(g.c + 3, (unsigned long long)w.tri);
     atomicAdd(g.c + 4, (unsigned long long)w.sph); atomicAdd(g.c + 5, (unsigned long long)w.accepted);
+    atomicAdd(g.c + 6, (unsigned long long)w.content);
 }
 RTX_DEV void add_counters(Counters, const Work<false>&) {}
 
@@ -205,12 +347,15 @@ k_trace_api(DScene s, const double* __restrict__ origin, const double* __restric
     }
 }
 
-// shootRay for a queue: reads (o, d), writes (hit_prim, hit_depth)
-template <bool COUNT>
+// shootRay for a queue: reads (o, d), writes (hit_prim, hit_depth).
+// MODE 0: the reference's walk order; 1: culled walk, closest hit; 2: culled walk, any hit
+// with depth <= limit[i] (depth = +inf when there is none).
+template <bool COUNT, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
              const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
-             uint32_t n, uint32_t linear, int32_t* hit_prim, double* hit_depth, Counters g)
+             const double* __restrict__ limit, uint32_t n, uint32_t linear, int32_t* hit_prim, double* hit_depth,
+             Counters g)
 {
     __shared__ int32_t stack[kStack * kBlock];
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -218,7 +363,12 @@ k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__
     d3 o = mk(ox[i], oy[i], oz[i]), d = mk(dx[i], dy[i], dz[i]);
     Work<COUNT> w;
     int32_t bp; double bd;
-    trace_lane<COUNT>(s, o, d, linear != 0, stack + threadIdx.x, bp, bd, w, nullptr, 0);
+    if (MODE == 0 || linear != 0 || !culling_is_exact(o, d))
+        trace_lane<COUNT>(s, o, d, linear != 0, stack + threadIdx.x, bp, bd, w, nullptr, 0);
+    else if (MODE == 1)
+        trace_lane_culled<COUNT, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w);
+    else
+        trace_lane_culled<COUNT, true>(s, o, d, limit[i], stack + threadIdx.x, bp, bd, w);
     if (hit_prim) hit_prim[i] = bp;
     hit_depth[i] = bd;
     add_counters(g, w);
@@ -419,6 +569,7 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
                 Ray lr = light_ray(l, from, u0, u1);
                 sq.ox[k] = lr.o.x; sq.oy[k] = lr.o.y; sq.oz[k] = lr.o.z;
                 sq.dx[k] = lr.d.x; sq.dy[k] = lr.d.y; sq.dz[k] = lr.d.z;
+                sq.limit[k] = light_distance(l, lr);
             }
         }
         q.counter[i] = rng.counter;       // the refraction child continues this stream

@@ -1,0 +1,86 @@
+"""Multi-GPU partitioning of the trace loop: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on MI355X; "gloo" on CPU for tests).
+
+Every pixel, sub-sample and frame is independent given the read-only scene (this is what
+the reference's parallel_for over pixels exploits, Raytracer/Raytracer.cpp:672), so the
+scene is replicated and the only exchange step is gathering finished framebuffer pieces on
+rank 0.  Two partitions:
+
+  bands   one frame split into interleaved bands of rows: band b belongs to rank b % world.
+          Interleaving evens out the very different cost of sky, floor and glass pixels.
+  frames  a frame sequence split round-robin: frame f belongs to rank f % world.
+
+The random streams are keyed by the global pixel index, so an image does not depend on how
+it was partitioned.
+"""
+import torch
+import torch.distributed as dist
+
+
+def band_rects(width, height, world, rank, band_rows=64):
+    """(x0, y0, w, h) of the bands owned by `rank`, top to bottom in frame order."""
+    rects = []
+    for b, y0 in enumerate(range(0, height, band_rows)):
+        if b % world == rank:
+            rects.append((0, y0, width, min(band_rows, height - y0)))
+    return rects
+
+
+def frames_for_rank(n_frames, world, rank):
+    return list(range(rank, n_frames, world))
+
+
+def _gather_to_rank0(local, world, rank, group=None):
+    """Gather equally shaped tensors on rank 0 (a list of `world` tensors there, None elsewhere)."""
+    if world == 1:
+        return [local]
+    out = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    dist.gather(local, out, dst=0, group=group)
+    return out
+
+
+def render_frame_bands(render_rect, width, height, device, band_rows=64, group=None):
+    """Render one frame cooperatively.
+
+    render_rect(x0, y0, w, h, out) must accumulate the rectangle's float32 RGB into `out`
+    (a [h, w, 3] tensor on `device`, zero-initialised here).  Returns the assembled
+    [height, width, 3] frame on rank 0 and None on the other ranks.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_bands = (height + band_rows - 1) // band_rows
+    per_rank = (n_bands + world - 1) // world
+    # every rank packs its bands into the same padded shape so that one gather moves them
+    packed = torch.zeros((per_rank, band_rows, width, 3), dtype=torch.float32, device=device)
+    mine = band_rects(width, height, world, rank, band_rows)
+    for k, (x0, y0, w, h) in enumerate(mine):
+        render_rect(x0, y0, w, h, packed[k, :h])
+    parts = _gather_to_rank0(packed, world, rank, group)
+    if rank != 0:
+        return None
+    frame = torch.empty((height, width, 3), dtype=torch.float32, device=device)
+    for r in range(world):
+        for k, (x0, y0, w, h) in enumerate(band_rects(width, height, world, r, band_rows)):
+            frame[y0:y0 + h] = parts[r][k, :h]
+    return frame
+
+
+def render_sequence_frames(render_frame, n_frames, width, height, device, group=None):
+    """Render frames 0..n_frames-1 round-robin.  render_frame(f, out) fills the [H, W, 3]
+    float32 tensor `out`.  Rank 0 returns the list of all frames in order, others None."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    rounds = (n_frames + world - 1) // world
+    frames = [None] * n_frames if rank == 0 else None
+    buf = torch.zeros((height, width, 3), dtype=torch.float32, device=device)
+    for k in range(rounds):
+        f = k * world + rank
+        buf.zero_()
+        if f < n_frames:
+            render_frame(f, buf)
+        parts = _gather_to_rank0(buf, world, rank, group)
+        if rank == 0:
+            for r in range(world):
+                if k * world + r < n_frames:
+                    frames[k * world + r] = parts[r].clone()
+    return frames

@@ -33,7 +33,7 @@ def test_whitted_point_light_depth1(gpu):
     scene, cam = scenes.whitted_scene()
     desc = scene.frame(0.0)
     rd = scenes.render_desc(160, 120, integrator=abi.INTEGRATOR_WHITTED, camera=cam, max_depth=1, bias=1e-3,
-                            flags=abi.FLAG_COUNTERS)
+                            flags=abi.FLAG_COUNTERS | abi.FLAG_REFERENCE_ORDER)
     img, stats, ref, ref_stats = _both(gpu, desc, rd)
     _same_ray_counts(stats, ref_stats)
     assert stats.rays_shadow > 0 and stats.rays_secondary > 0
@@ -59,11 +59,46 @@ def test_mesh_directional_light_hard_shadows(gpu):
     scene, cam = scenes.mesh_scene(slices=100, stacks=50)
     desc = scene.frame(0.0)
     rd = scenes.render_desc(192, 108, integrator=abi.INTEGRATOR_WHITTED, camera=cam, max_depth=3, bias=1e-2,
-                            clear=(0.21, 0.78, 0.95), flags=abi.FLAG_COUNTERS)
+                            clear=(0.21, 0.78, 0.95), flags=abi.FLAG_COUNTERS | abi.FLAG_REFERENCE_ORDER)
     img, stats, ref, ref_stats = _both(gpu, desc, rd)
     _same_ray_counts(stats, ref_stats)
     assert stats.branch_visits == ref_stats.branch_visits and stats.aabb_tests == ref_stats.aabb_tests
     assert rel_err(img, ref).max() < REL_TOL
+
+
+def _scene_cases():
+    yield "whitted", scenes.whitted_scene, dict(integrator=abi.INTEGRATOR_WHITTED, max_depth=3, bias=1e-3)
+    yield "mesh", lambda: scenes.mesh_scene(slices=100, stacks=50), dict(integrator=abi.INTEGRATOR_WHITTED,
+                                                                        max_depth=3, bias=1e-2)
+    yield "mesh_soft", lambda: scenes.mesh_scene(slices=60, stacks=30, ggx=True, square_light=True), dict(
+        integrator=abi.INTEGRATOR_WHITTED, n=2, light_n=2, max_depth=2, bias=1e-2)
+    yield "live_path", scenes.live_scene, dict(integrator=abi.INTEGRATOR_PATH, n=2, max_depth=8, bias=1e-4)
+    yield "lens_path", scenes.lens_scene, dict(integrator=abi.INTEGRATOR_PATH, n=2, max_depth=8, bias=1e-4,
+                                               clear=(0.2, 0.7, 0.9))
+    yield "mesh_path", lambda: scenes.mesh_scene(slices=60, stacks=30, ggx=True), dict(
+        integrator=abi.INTEGRATOR_PATH, n=2, max_depth=4, bias=1e-4, clear=(2.0, 2.0, 2.0))
+
+
+@pytest.mark.parametrize("name,make,kw", list(_scene_cases()), ids=[c[0] for c in _scene_cases()])
+def test_culled_walk_gives_identical_images(gpu, name, make, kw):
+    """The default render path skips KD nodes that cannot change the closest hit and stops
+    shadow rays at the first occluder; its images must be bit-identical to the ones produced
+    by walking the tree exactly as the reference does, with far fewer box tests."""
+    scene, cam = make()
+    desc = scene.frame(0.3)
+    kw = dict(kw)
+    flags = kw.pop("flags", 0)
+    fast = scenes.render_desc(144, 96, camera=cam, seed=9, flags=flags | abi.FLAG_COUNTERS, **kw)
+    slow = scenes.render_desc(144, 96, camera=cam, seed=9,
+                              flags=flags | abi.FLAG_COUNTERS | abi.FLAG_REFERENCE_ORDER, **kw)
+    with gpu.DeviceScene(desc) as ds:
+        a, sa = ds.render(fast)
+        b, sb = ds.render(slow)
+    assert np.array_equal(a, b)
+    _same_ray_counts(sa, sb)
+    assert sb.content_tests == 0
+    if desc.n_branches > 100:
+        assert sa.aabb_tests + sa.content_tests + sa.branch_visits < sb.aabb_tests + sb.branch_visits
 
 
 def test_square_light_soft_shadows_multisample(gpu):

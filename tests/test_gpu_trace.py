@@ -27,7 +27,7 @@ def test_live_scene_hit_hash(gpu, t, want):
     with gpu.DeviceScene(desc) as ds:
         got = ds.trace_closest(o, d, leaf_seq_cap=16, want_counters=True)
     assert id_hash(got["prim"]) == want
-    compare_trace(got, orc.trace_closest(desc, o, d, leaf_seq_cap=16, want_counters=True), seq_cap=16)
+    compare_trace(got, orc.trace_closest(desc, o, d, leaf_seq_cap=16, want_counters=True), seq_cap=16, desc=desc)
 
 
 def test_live_scene_random_and_edge_rays(gpu):
@@ -47,8 +47,8 @@ def test_live_scene_random_and_edge_rays(gpu):
     with gpu.DeviceScene(desc) as ds:
         got = ds.trace_closest(o, d, leaf_seq_cap=24, want_counters=True)
         lin = ds.trace_closest(o, d, flags=abi.FLAG_LINEAR_SCAN, want_counters=True)
-    compare_trace(got, orc.trace_closest(desc, o, d, leaf_seq_cap=24, want_counters=True), seq_cap=24)
-    compare_trace(lin, orc.trace_closest(desc, o, d, flags=abi.FLAG_LINEAR_SCAN, want_counters=True))
+    compare_trace(got, orc.trace_closest(desc, o, d, leaf_seq_cap=24, want_counters=True), seq_cap=24, desc=desc)
+    compare_trace(lin, orc.trace_closest(desc, o, d, flags=abi.FLAG_LINEAR_SCAN, want_counters=True), desc=desc)
     assert (got["prim"][-1000:] == -1).all()
 
 
@@ -65,7 +65,7 @@ def test_mesh_scene_primary_and_shadow_like_rays(gpu):
     with gpu.DeviceScene(desc) as ds:
         got = ds.trace_closest(o, d, leaf_seq_cap=64, want_counters=True)
     want = orc.trace_closest(desc, o, d, leaf_seq_cap=64, want_counters=True)
-    compare_trace(got, want, seq_cap=64)
+    compare_trace(got, want, seq_cap=64, desc=desc)
     assert (got["prim"] >= 0).mean() > 0.3
 
 
@@ -82,7 +82,7 @@ def test_lens_scene_biconvex(gpu):
     with gpu.DeviceScene(desc) as ds:
         got = ds.trace_closest(o, d, leaf_seq_cap=8, want_counters=True)
     want = orc.trace_closest(desc, o, d, leaf_seq_cap=8, want_counters=True)
-    compare_trace(got, want, seq_cap=8)
+    compare_trace(got, want, seq_cap=8, desc=desc)
     assert (got["prim"] >= desc.n_shapes).any(), "no ray reported an inner lens sphere"
 
 
@@ -94,7 +94,7 @@ def test_empty_and_single_ray(gpu):
         assert got["prim"].size == 0
         one = ds.trace_closest(np.array([[0.0, 3.0, 9.0]]), np.array([[0.0, -0.2, -1.0]]), want_counters=True)
     want = orc.trace_closest(desc, np.array([[0.0, 3.0, 9.0]]), np.array([[0.0, -0.2, -1.0]]), want_counters=True)
-    compare_trace(one, want)
+    compare_trace(one, want, desc=desc)
 
 
 def test_malformed_scene_is_rejected(gpu):

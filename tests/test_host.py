@@ -1,0 +1,127 @@
+"""Host scene API: KD construction (KDTree.cpp:68-126), flattening, and the oracle's KD walk
+against its own linear scan (the reference's KDTRACE toggle, Raytracer.cpp:114-118)."""
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, scenes
+from raytracer_amd.host import HostScene, desc_array
+from oracle import binding as orc
+from helpers import camera_rays_np
+
+
+def _tree_arrays(desc):
+    return dict(
+        lesser=desc_array(desc, "branch_lesser", desc.n_branches, np.int32),
+        greater=desc_array(desc, "branch_greater", desc.n_branches, np.int32),
+        axis=desc_array(desc, "branch_axis", desc.n_branches, np.int32),
+        value=desc_array(desc, "branch_value", desc.n_branches, np.float64),
+        bmin=desc_array(desc, "branch_min", desc.n_branches * 3, np.float64).reshape(-1, 3),
+        bmax=desc_array(desc, "branch_max", desc.n_branches * 3, np.float64).reshape(-1, 3),
+        first=desc_array(desc, "leaf_first", desc.n_leaves, np.uint32),
+        count=desc_array(desc, "leaf_count", desc.n_leaves, np.uint32),
+        refs=desc_array(desc, "leaf_refs", desc.n_leaf_refs, np.uint32),
+    )
+
+
+def test_small_scene_is_a_single_leaf():
+    """Fewer than 7 shapes -> buildKDTree returns a KDLeaf (KDTree.cpp:69)."""
+    scene, _ = scenes.whitted_scene()
+    desc = scene.frame(0.0)
+    assert desc.kd_root == -1 and desc.n_branches == 0 and desc.n_leaves == 1
+    assert desc_array(desc, "leaf_refs", desc.n_leaf_refs, np.uint32).tolist() == [0, 1, 2, 3]
+
+
+def test_tree_structure_invariants():
+    scene, _ = scenes.mesh_scene(slices=40, stacks=20)
+    desc = scene.frame(0.0)
+    t = _tree_arrays(desc)
+    st = scene.kd_stats()
+    assert st["depth"] <= 22 and st["branches"] == desc.n_branches
+    # leaves are numbered in walk order (lesser first) and their ranges tile leaf_refs
+    assert (t["first"][1:] == t["first"][:-1] + t["count"][:-1]).all()
+    order = []
+
+    def walk(node):
+        if node < 0:
+            order.append(~node)
+            return
+        ax, v = t["axis"][node], t["value"][node]
+        # child boxes clip the parent box at the split value (KDTree.cpp:85-86,107-108)
+        for child, lo in ((t["lesser"][node], True), (t["greater"][node], False)):
+            if child >= 0:
+                if lo:
+                    assert t["bmax"][child][ax] == v
+                else:
+                    assert t["bmin"][child][ax] == v
+                assert t["axis"][child] == (ax + 1) % 3
+        walk(t["lesser"][node])
+        walk(t["greater"][node])
+
+    import sys
+    sys.setrecursionlimit(10000)
+    walk(desc.kd_root)
+    assert order == list(range(desc.n_leaves))
+    # every shape is referenced by at least one leaf; the root box contains the origin (AABB(0,0) + encompass)
+    assert set(t["refs"].tolist()) == set(range(desc.n_shapes))
+    assert (t["bmin"][0] <= 0).all() and (t["bmax"][0] >= 0).all()
+
+
+def test_kd_walk_equals_linear_scan_up_to_depth_ties():
+    scene, cam = scenes.mesh_scene(slices=60, stacks=30)
+    desc = scene.frame(0.0)
+    rd = scenes.render_desc(160, 90, camera=cam)
+    o, d = camera_rays_np(rd)
+    kd = orc.trace_closest(desc, o, d)
+    lin = orc.trace_closest(desc, o, d, flags=abi.FLAG_LINEAR_SCAN)
+    assert np.array_equal(kd["depth"], lin["depth"])
+    differ = kd["prim"] != lin["prim"]
+    assert differ.mean() < 0.01          # exact depth ties on shared edges go to the first shape in walk order
+
+
+def test_animated_spheres_move_between_frames():
+    scene, _ = scenes.live_scene()
+    a = desc_array(scene.frame(0.0), "sphere_center", 24, np.float64).copy()
+    b = desc_array(scene.frame(1.0), "sphere_center", 24, np.float64).copy()
+    assert np.array_equal(a[:15], b[:15])            # noMovement spheres
+    assert not np.array_equal(a[15:], b[15:])        # circle0/1/2
+    assert np.allclose(b[15:].reshape(3, 3)[:, 1], 15.0)
+
+
+def test_biconvex_hidden_spheres_and_box():
+    s = HostScene()
+    s.sphere((5, 0, 0), 1.0, s.material("Red"))
+    s.biconvex((0.0, 2.0, 4.0), (0.0, 0.0, 2.0), 3.0, 50.0)
+    desc = s.frame(0.0)
+    assert desc.n_shapes == 2 and desc.n_prims == 4 and desc.n_lenses == 1
+    ptype = desc_array(desc, "prim_type", 4, np.uint8).tolist()
+    assert ptype == [abi.PRIM_SPHERE, abi.PRIM_BICONVEX, abi.PRIM_SPHERE, abi.PRIM_SPHERE]
+    assert desc_array(desc, "lens_spheres", 2, np.uint32).tolist() == [2, 3]
+    # d = n r^2 / (f (n-1)^2) with n = 1.54 (Biconvex.cpp:3-10,31); centres at origin -/+ forward*(r-d)
+    d = 1.54 * 9.0 / (50.0 * 0.54 * 0.54)
+    c = desc_array(desc, "sphere_center", 9, np.float64).reshape(3, 3)
+    assert np.allclose(c[1], [0.0, 2.0, 4.0 - (3.0 - d)]) and np.allclose(c[2], [0.0, 2.0, 4.0 + (3.0 - d)])
+    half = np.sqrt((3.0 - d / 2) * 8.0 * d) / 2.0
+    bmin = desc_array(desc, "prim_aabb_min", 12, np.float64).reshape(4, 3)[1]
+    assert np.allclose(bmin, np.array([0.0, 2.0, 4.0]) - half)
+    # the glass of the inner spheres is the preset (Biconvex.cpp:30)
+    glass = desc.materials[desc_array(desc, "prim_material", 4, np.uint32)[2]]
+    assert (glass.ni, glass.transparency) == (1.54, 0.8)
+
+
+def test_unknown_preset_is_an_error_not_a_crash():
+    s = HostScene()
+    with pytest.raises(RuntimeError):
+        s.material("NoSuchPreset")
+
+
+def test_texture_and_sampler_descriptors():
+    s = HostScene()
+    tex = s.texture(scenes.checker_texture(size=16, cells=2))
+    m = s.material_custom((1, 1, 1), samplers={"color": (abi.SAMPLER_TEXTURE_VEC3, tex),
+                                              "smoothness": (abi.SAMPLER_DOUBLE_CHECKERS, 0)})
+    s.sphere((0, 0, 0), 1.0, m)
+    desc = s.frame(0.0)
+    assert desc.n_textures == 1 and desc.textures[0].width == 16 and desc.n_texel_bytes == 16 * 16 * 3
+    mat = desc.materials[0]
+    assert mat.color_fn.kind == abi.SAMPLER_TEXTURE_VEC3 and mat.smoothness_fn.kind == abi.SAMPLER_DOUBLE_CHECKERS
+    assert mat.ns_fn.kind == abi.SAMPLER_CONST
