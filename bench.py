@@ -45,9 +45,11 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--walk", choices=["culled", "reference"], default="culled",
-                    help="culled: skip KD nodes that cannot change the result (default render path); "
-                         "reference: walk node for node as the reference's traverseKDTree")
+    ap.add_argument("--walk", choices=["bvh", "kd-culled", "reference"], default="bvh",
+                    help="bvh: candidates from the library's BVH, verified against the reference's KD walk "
+                         "(default render path); kd-culled: the reference's KD tree walked with culling; "
+                         "reference: node for node as the reference's traverseKDTree.  All three give "
+                         "identical images.")
     args = ap.parse_args()
 
     import torch
@@ -72,7 +74,7 @@ def main():
     scene, _ = scenes.mesh_scene()
     desc = scene.frame(0.0)
     kd = scene.kd_stats()
-    kflags = {"culled": 0, "reference": abi.FLAG_REFERENCE_ORDER}[args.walk]
+    kflags = {"bvh": 0, "kd-culled": abi.FLAG_KD_CULLED, "reference": abi.FLAG_REFERENCE_ORDER}[args.walk]
     stream = torch.cuda.current_stream().cuda_stream
     ds = device.DeviceScene(desc, stream=stream)
 

@@ -191,7 +191,14 @@ enum {
                                            hit and stops shadow rays at the first occluder;
                                            hit ids, depths and images are identical, only
                                            the work (and the counters) shrink             */
-    RTX_FLAG_STAGE_TIMES     = 1u << 7  /* fill the per-stage ms_* fields of rtx_stats     */
+    RTX_FLAG_KD_CULLED       = 1u << 6, /* find candidates by walking the reference's KD
+                                           tree with culling instead of through the
+                                           library's own BVH (same results; for comparison) */
+    RTX_FLAG_STAGE_TIMES     = 1u << 7, /* fill the per-stage ms_* fields of rtx_stats     */
+    RTX_FLAG_RENDER_WALK     = 1u << 8  /* rtx_trace_closest only: use the render path's
+                                           walk instead of the reference-order one; the
+                                           leaf outputs and counters then describe that
+                                           walk's own work, not the reference's            */
 };
 
 /* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;
@@ -269,7 +276,8 @@ void rtx_scene_destroy(rtx_scene* scene);
  *   leaf_count[i]  number of KDLeaf visits      leaf_hash[i]  FNV-1a-64 over the leaf ids
  *   leaf_seq       [n*leaf_seq_cap] first leaf ids visited, rest untouched
  *   counters       [n*6] branch, leaf, aabb, triangle, sphere, accepted per ray
- * flags: RTX_FLAG_LINEAR_SCAN.  This entry point always walks in the reference's order.
+ * flags: RTX_FLAG_LINEAR_SCAN; RTX_FLAG_RENDER_WALK (optionally with RTX_FLAG_KD_CULLED).
+ * Without RTX_FLAG_RENDER_WALK the walk is the reference's, node for node.
  */
 int rtx_trace_closest(rtx_scene* scene, const double* origin, const double* direction, size_t n,
                       uint32_t flags, int32_t* prim, double* depth, double* position,

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "rtx_kernels.hpp"
+#include "rtx_bvh.hpp"
 
 using namespace rtx;
 
@@ -110,6 +111,7 @@ struct rtx_scene {
     hipStream_t stream = nullptr;
     int device = 0;
     uint32_t kd_depth = 0;
+    uint32_t bvh_depth = 0;
 };
 
 namespace {
@@ -351,6 +353,7 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
         for (uint32_t r = 0; r < s->leaf_count[i]; ++r) grow(c, boxes[s->leaf_refs[s->leaf_first[i] + r]]);
         leaf_cbox[i] = c;
     }
+    std::vector<uint32_t> leaf_lo(s->n_branches, 0);
     {
         // children before parents: explicit post-order walk (the tree was validated above)
         std::vector<std::pair<int32_t, int>> st;
@@ -369,9 +372,53 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
                 for (int32_t ch : {s->branch_lesser[node], s->branch_greater[node]})
                     grow(c, ch >= 0 ? branch_cbox[ch] : leaf_cbox[(uint32_t)~ch]);
                 branch_cbox[node] = c;
+                // leaf-id range of the subtree (leaves are numbered in walk order, so it is contiguous)
+                int32_t g = s->branch_greater[node];
+                branches[node].leaf_mid = g >= 0 ? leaf_lo[g] : (uint32_t)~g;
+                branches[node].leaf_hi = g >= 0 ? branches[g].leaf_hi : (uint32_t)~g + 1;
+                int32_t l = s->branch_lesser[node];
+                leaf_lo[node] = l >= 0 ? leaf_lo[l] : (uint32_t)~l;
             }
         }
     }
+    // the numbering the verification relies on: every subtree's leaves are consecutive
+    for (uint32_t i = 0; i < s->n_branches; ++i) {
+        int32_t l = s->branch_lesser[i];
+        uint32_t l_hi = l >= 0 ? branches[l].leaf_hi : (uint32_t)~l + 1;
+        if (l_hi != branches[i].leaf_mid || branches[i].leaf_hi <= branches[i].leaf_mid) {
+            delete sc;
+            return fail(RTX_ERR_INVALID, "KD leaves are not numbered in walk order (branch %u)", i);
+        }
+    }
+    // inverse leaf index: for every shape the leaves that reference it, in increasing order
+    std::vector<uint32_t> prim_leaf_first(s->n_shapes + 1, 0), prim_leaf_ids(s->n_leaf_refs), prim_leaf_pos(s->n_leaf_refs);
+    for (uint32_t r = 0; r < s->n_leaf_refs; ++r) prim_leaf_first[s->leaf_refs[r] + 1]++;
+    for (uint32_t p = 0; p < s->n_shapes; ++p) prim_leaf_first[p + 1] += prim_leaf_first[p];
+    {
+        std::vector<uint32_t> cursor(prim_leaf_first.begin(), prim_leaf_first.end() - 1);
+        for (uint32_t leaf = 0; leaf < s->n_leaves; ++leaf)
+            for (uint32_t r = 0; r < s->leaf_count[leaf]; ++r) {
+                uint32_t pos = s->leaf_first[leaf] + r, p = s->leaf_refs[pos];
+                // a shape listed twice in one leaf keeps its first position
+                if (cursor[p] > prim_leaf_first[p] && prim_leaf_ids[cursor[p] - 1] == leaf) continue;
+                prim_leaf_ids[cursor[p]] = leaf; prim_leaf_pos[cursor[p]] = pos; cursor[p]++;
+            }
+        // compact away slots left by duplicates
+        bool dup = false;
+        for (uint32_t p = 0; p < s->n_shapes; ++p) if (cursor[p] != prim_leaf_first[p + 1]) dup = true;
+        if (dup) {
+            std::vector<uint32_t> nf(s->n_shapes + 1, 0), ni, np;
+            for (uint32_t p = 0; p < s->n_shapes; ++p) {
+                for (uint32_t k = prim_leaf_first[p]; k < cursor[p]; ++k) { ni.push_back(prim_leaf_ids[k]); np.push_back(prim_leaf_pos[k]); }
+                nf[p + 1] = (uint32_t)ni.size();
+            }
+            prim_leaf_first.swap(nf); prim_leaf_ids.swap(ni); prim_leaf_pos.swap(np);
+        }
+    }
+    BvhBuild bvh;
+    build_bvh(boxes, s->n_shapes, bvh);
+    d.bvh_root = bvh.root;
+    sc->bvh_depth = (uint32_t)bvh.depth;
     double scale = 0.0;
     for (const PrimBox& b : boxes)
         for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(b.bmin[k]), std::fabs(b.bmax[k])));
@@ -383,6 +430,12 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     up(branches.data(), branches.size(), &d.branches);
     up(branch_cbox.data(), branch_cbox.size(), &d.branch_cbox);
     up(leaf_cbox.data(), leaf_cbox.size(), &d.leaf_cbox);
+    up(bvh.nodes.data(), bvh.nodes.size(), &d.bvh_nodes);
+    up(bvh.leaves.data(), bvh.leaves.size(), &d.bvh_leaves);
+    up(bvh.prims.data(), bvh.prims.size(), &d.bvh_prims);
+    up(prim_leaf_first.data(), prim_leaf_first.size(), &d.prim_leaf_first);
+    up(prim_leaf_ids.data(), prim_leaf_ids.size(), &d.prim_leaf_ids);
+    up(prim_leaf_pos.data(), prim_leaf_pos.size(), &d.prim_leaf_pos);
     up(leaves.data(), leaves.size(), &d.leaves);
     up(s->leaf_refs, (size_t)s->n_leaf_refs, &d.leaf_refs);
     up(boxes.data(), boxes.size(), &d.prim_box);
@@ -451,9 +504,14 @@ int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* directi
         HIP_TRY(hipMemcpy(d_seq, leaf_seq, n * (size_t)leaf_seq_cap * 4, hipMemcpyHostToDevice));
     }
     if (counters) HIP_TRY(dalloc(n * 24, (void**)&d_ctr));
-    hipLaunchKernelGGL(k_trace_api, grid_for(n), dim3(kBlock), 0, sc->stream, sc->d, d_o, d_d, (uint32_t)n,
-                       (flags & RTX_FLAG_LINEAR_SCAN) ? 1u : 0u, d_prim, d_depth, d_pos, d_nrm, d_uv, d_bary, d_lc, d_lh,
-                       d_seq, leaf_seq_cap, d_ctr);
+    const uint32_t linear = (flags & RTX_FLAG_LINEAR_SCAN) ? 1u : 0u;
+#define RTX_LAUNCH_API(MODE)                                                                                      \
+    hipLaunchKernelGGL(k_trace_api<MODE>, grid_for(n), dim3(kBlock), 0, sc->stream, sc->d, d_o, d_d, (uint32_t)n, \
+                       linear, d_prim, d_depth, d_pos, d_nrm, d_uv, d_bary, d_lc, d_lh, d_seq, leaf_seq_cap, d_ctr)
+    if (!(flags & RTX_FLAG_RENDER_WALK) || linear) RTX_LAUNCH_API(0);
+    else if (flags & RTX_FLAG_KD_CULLED) RTX_LAUNCH_API(1);
+    else RTX_LAUNCH_API(3);
+#undef RTX_LAUNCH_API
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(sc->stream));
     HIP_TRY(hipMemcpy(prim, d_prim, n * 4, hipMemcpyDeviceToHost));
@@ -475,18 +533,26 @@ static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const
                         int32_t* hit_prim, double* hit_depth, bool count)
 {
     uint32_t linear = (flags & RTX_FLAG_LINEAR_SCAN) ? 1u : 0u;
-    int mode = (flags & (RTX_FLAG_REFERENCE_ORDER | RTX_FLAG_LINEAR_SCAN)) ? 0 : (limit ? 2 : 1);
+    int mode;
+    if (flags & (RTX_FLAG_REFERENCE_ORDER | RTX_FLAG_LINEAR_SCAN)) mode = 0;
+    else if (flags & RTX_FLAG_KD_CULLED) mode = limit ? 2 : 1;
+    else mode = limit ? 4 : 3;
     Counters g;
     g.c = count ? sc->ws.work : nullptr;
     dim3 grid = grid_for(n), block(kBlock);
 #define RTX_LAUNCH_TRACE(COUNT, MODE)                                                                                  \
     hipLaunchKernelGGL((k_trace_pool<COUNT, MODE>), grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
                        linear, hit_prim, hit_depth, g)
-    if (count) {
-        if (mode == 0) RTX_LAUNCH_TRACE(true, 0); else if (mode == 1) RTX_LAUNCH_TRACE(true, 1); else RTX_LAUNCH_TRACE(true, 2);
-    } else {
-        if (mode == 0) RTX_LAUNCH_TRACE(false, 0); else if (mode == 1) RTX_LAUNCH_TRACE(false, 1); else RTX_LAUNCH_TRACE(false, 2);
+#define RTX_LAUNCH_MODES(COUNT)                                                                   \
+    switch (mode) {                                                                               \
+    case 0: RTX_LAUNCH_TRACE(COUNT, 0); break;                                                    \
+    case 1: RTX_LAUNCH_TRACE(COUNT, 1); break;                                                    \
+    case 2: RTX_LAUNCH_TRACE(COUNT, 2); break;                                                    \
+    case 3: RTX_LAUNCH_TRACE(COUNT, 3); break;                                                    \
+    default: RTX_LAUNCH_TRACE(COUNT, 4); break;                                                   \
     }
+    if (count) { RTX_LAUNCH_MODES(true) } else { RTX_LAUNCH_MODES(false) }
+#undef RTX_LAUNCH_MODES
 #undef RTX_LAUNCH_TRACE
     HIP_TRY(hipGetLastError());
     return RTX_OK;

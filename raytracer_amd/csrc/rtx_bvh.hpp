@@ -1,0 +1,161 @@
+// rtx_bvh.hpp -- host-side construction of the candidate-finding BVH and of the
+// inverse leaf index used to verify candidates against the reference's KD walk.
+//
+// The reference's KD tree (KDTree.cpp:68-126) duplicates every shape into dozens of
+// leaves and mixes far-apart shapes in one leaf, so it is a poor structure for
+// *finding* the shapes a ray can hit.  The library therefore also builds a
+// conventional bounding-volume hierarchy over the shape boxes (binned surface-area
+// heuristic, at most 4 shapes per leaf, depth-capped so the traversal stack is bounded).
+// The BVH never decides a result on its own: a shape it finds is accepted only after
+// the device code has shown that traverseKDTree would have visited a leaf holding it.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <numeric>
+#include <vector>
+
+#include "rtx_device.hpp"
+
+namespace rtx {
+
+constexpr int kBvhMaxDepth = 30;        // traversal stack is 32 entries
+constexpr uint32_t kBvhLeafSize = 4;
+
+struct BvhBuild {
+    std::vector<BvhNode> nodes;
+    std::vector<uint2> leaves;          // (first, count) into prims
+    std::vector<uint32_t> prims;
+    int32_t root = 0;                   // >= 0 node, < 0 leaf ~root; kBvhEmpty when there are no shapes
+    int depth = 0;
+};
+
+namespace bvh_detail {
+
+struct Box {
+    double mn[3], mx[3];
+    void reset() { for (int k = 0; k < 3; ++k) { mn[k] = std::numeric_limits<double>::max(); mx[k] = -mn[k]; } }
+    void grow(const PrimBox& b) { for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], b.bmin[k]); mx[k] = std::max(mx[k], b.bmax[k]); } }
+    void grow(const Box& b) { for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], b.mn[k]); mx[k] = std::max(mx[k], b.mx[k]); } }
+    void grow_point(const double* p) { for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], p[k]); mx[k] = std::max(mx[k], p[k]); } }
+    double area() const {
+        double d0 = mx[0] - mn[0], d1 = mx[1] - mn[1], d2 = mx[2] - mn[2];
+        if (d0 < 0 || d1 < 0 || d2 < 0) return 0.0;
+        return 2.0 * (d0 * d1 + d1 * d2 + d2 * d0);
+    }
+};
+
+struct Builder {
+    const std::vector<PrimBox>& boxes;
+    std::vector<double> centroid;       // 3 per prim
+    std::vector<uint32_t> order;
+    BvhBuild& out;
+
+    Builder(const std::vector<PrimBox>& b, uint32_t n, BvhBuild& o) : boxes(b), centroid(3 * (size_t)n), order(n), out(o)
+    {
+        for (uint32_t i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k) centroid[3 * (size_t)i + k] = 0.5 * (b[i].bmin[k] + b[i].bmax[k]);
+        std::iota(order.begin(), order.end(), 0u);
+    }
+
+    Box bounds(uint32_t lo, uint32_t hi) const
+    {
+        Box b; b.reset();
+        for (uint32_t i = lo; i < hi; ++i) b.grow(boxes[order[i]]);
+        return b;
+    }
+
+    int32_t make_leaf(uint32_t lo, uint32_t hi)
+    {
+        uint32_t id = (uint32_t)out.leaves.size();
+        out.leaves.push_back(make_uint2((uint32_t)out.prims.size(), hi - lo));
+        for (uint32_t i = lo; i < hi; ++i) out.prims.push_back(order[i]);
+        return ~(int32_t)id;
+    }
+
+    // returns the split position in [lo+1, hi-1]
+    uint32_t split(uint32_t lo, uint32_t hi, int depth)
+    {
+        const uint32_t n = hi - lo;
+        // levels left must be able to hold n shapes in leaves of kBvhLeafSize by halving
+        int need = 0;
+        for (uint64_t cap = kBvhLeafSize; cap < n; cap *= 2) ++need;
+        bool force_median = need >= kBvhMaxDepth - depth;
+        Box cb; cb.reset();
+        for (uint32_t i = lo; i < hi; ++i) cb.grow_point(&centroid[3 * (size_t)order[i]]);
+        int axis = 0;
+        double ext = -1.0;
+        for (int k = 0; k < 3; ++k) if (cb.mx[k] - cb.mn[k] > ext) { ext = cb.mx[k] - cb.mn[k]; axis = k; }
+        auto median = [&]() {
+            uint32_t mid = lo + n / 2;
+            std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi, [&](uint32_t a, uint32_t b) {
+                double ca = centroid[3 * (size_t)a + axis], cb2 = centroid[3 * (size_t)b + axis];
+                return ca < cb2 || (ca == cb2 && a < b);
+            });
+            return mid;
+        };
+        if (force_median || !(ext > 0.0)) return median();
+        // binned SAH on the widest centroid axis
+        constexpr int kBins = 16;
+        Box bin_box[kBins];
+        uint32_t bin_count[kBins] = {0};
+        for (int b = 0; b < kBins; ++b) bin_box[b].reset();
+        const double scale = kBins / ext;
+        auto bin_of = [&](uint32_t prim) {
+            int b = (int)((centroid[3 * (size_t)prim + axis] - cb.mn[axis]) * scale);
+            return std::min(std::max(b, 0), kBins - 1);
+        };
+        for (uint32_t i = lo; i < hi; ++i) { int b = bin_of(order[i]); bin_box[b].grow(boxes[order[i]]); bin_count[b]++; }
+        double left_area[kBins], right_area[kBins];
+        uint32_t left_n[kBins], right_n[kBins];
+        Box acc; acc.reset(); uint32_t cnt = 0;
+        for (int b = 0; b < kBins; ++b) { if (bin_count[b]) acc.grow(bin_box[b]); cnt += bin_count[b]; left_area[b] = acc.area(); left_n[b] = cnt; }
+        acc.reset(); cnt = 0;
+        for (int b = kBins - 1; b >= 0; --b) { if (bin_count[b]) acc.grow(bin_box[b]); cnt += bin_count[b]; right_area[b] = acc.area(); right_n[b] = cnt; }
+        double best = std::numeric_limits<double>::max();
+        int best_b = -1;
+        for (int b = 0; b + 1 < kBins; ++b) {
+            if (left_n[b] == 0 || right_n[b + 1] == 0) continue;
+            double cost = left_area[b] * left_n[b] + right_area[b + 1] * right_n[b + 1];
+            if (cost < best) { best = cost; best_b = b; }
+        }
+        if (best_b < 0) return median();
+        auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](uint32_t p) { return bin_of(p) <= best_b; });
+        uint32_t mid = (uint32_t)(it - order.begin());
+        if (mid == lo || mid == hi) return median();
+        // keep the tree balanced enough for the depth budget
+        uint32_t small = std::min(mid - lo, hi - mid);
+        if ((uint64_t)small * 64 < n && need + 6 >= kBvhMaxDepth - depth) return median();
+        return mid;
+    }
+
+    int32_t build(uint32_t lo, uint32_t hi, int depth)
+    {
+        out.depth = std::max(out.depth, depth);
+        if (hi - lo <= kBvhLeafSize) return make_leaf(lo, hi);
+        uint32_t mid = split(lo, hi, depth);
+        uint32_t id = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        Box l = bounds(lo, mid), r = bounds(mid, hi);
+        int32_t left = build(lo, mid, depth + 1);
+        int32_t right = build(mid, hi, depth + 1);
+        BvhNode& n = out.nodes[id];
+        for (int k = 0; k < 3; ++k) { n.lbox.bmin[k] = l.mn[k]; n.lbox.bmax[k] = l.mx[k]; n.rbox.bmin[k] = r.mn[k]; n.rbox.bmax[k] = r.mx[k]; }
+        n.left = left; n.right = right;
+        return (int32_t)id;
+    }
+};
+
+}  // namespace bvh_detail
+
+inline void build_bvh(const std::vector<PrimBox>& boxes, uint32_t n_shapes, BvhBuild& out)
+{
+    out = BvhBuild();
+    if (n_shapes == 0) { out.root = kBvhEmpty; return; }
+    bvh_detail::Builder b(boxes, n_shapes, out);
+    out.nodes.reserve(n_shapes / 2 + 1);
+    out.root = b.build(0, n_shapes, 0);
+}
+
+}  // namespace rtx

@@ -96,13 +96,34 @@ struct Branch {                 // 80 bytes, 16-byte aligned
     int32_t axis;
     int32_t lesser;
     int32_t greater;
-    int32_t pad[3];
+    uint32_t leaf_mid;          // first leaf id of the greater subtree (leaves are numbered in walk order)
+    uint32_t leaf_hi;           // one past the last leaf id of this subtree
+    int32_t pad;
 };
 
 struct PrimBox { double bmin[3]; double bmax[3]; };   // 48 bytes
 
+// Candidate-finding BVH over the shape boxes (built by the library, see rtx_bvh.hpp):
+// a node carries both children's boxes; child >= 0 is a node, < 0 is leaf ~child.
+struct BvhNode {                // 112 bytes, 16-byte aligned
+    PrimBox lbox, rbox;
+    int32_t left, right;
+    int32_t pad[2];
+};
+constexpr int32_t kBvhEmpty = INT32_MIN;
+
 struct DScene {
     int32_t root;
+    int32_t bvh_root;
+    const BvhNode* bvh_nodes;
+    const uint2* bvh_leaves;        // (first, count) into bvh_prims
+    const uint32_t* bvh_prims;
+    // inverse leaf index: the KD leaves that reference shape p are
+    // prim_leaf_ids[prim_leaf_first[p] .. prim_leaf_first[p+1]) in increasing order, and
+    // prim_leaf_pos holds the shape's position in leaf_refs for each of them
+    const uint32_t* prim_leaf_first;
+    const uint32_t* prim_leaf_ids;
+    const uint32_t* prim_leaf_pos;
     uint32_t n_branches, n_leaves, n_leaf_refs, n_shapes, n_prims, n_lights, n_materials, n_textures;
     double scene_scale;             // largest |coordinate| of the scene box
     const Branch* branches;

@@ -17,7 +17,7 @@
 namespace rtx {
 
 constexpr int kBlock = 256;             // threads per workgroup (4 waves)
-constexpr int kStack = 24;              // per-lane KD stack entries (tree depth is capped at 21, KDTree.cpp:69)
+constexpr int kStack = 32;              // per-lane stack entries: KD depth is capped at 21 (KDTree.cpp:69), BVH depth at 30
 
 // ---- ray queue (SoA, resident in HBM) ---------------------------------------------------
 struct RayQueue {
@@ -299,6 +299,187 @@ RTX_DEV void trace_lane_culled(const DScene& s, d3 o, d3 d, double limit, int32_
     if constexpr (ANYHIT) { best_depth = kInf; best_prim = -1; }     // nothing at or before the light
 }
 
+// ---- BVH walk with membership verification: same answer, far less work ---------------------------
+// The candidates shootRay chooses from are the shapes S whose box test passes and whose
+// rayHit succeeds AND that sit in some leaf traverseKDTree visits for this ray.  The BVH
+// enumerates the first set (each shape once, nearest first, with the same box-miss and
+// distance culls as above, which are exact for any boxes that contain the shape boxes); the
+// second condition is then checked against the reference's own tree:
+//   * the walk order of leaves equals their numbering, and the inverse leaf index lists, per
+//     shape, the leaves that reference it in increasing order;
+//   * branch_predicate() evaluates which children traverseKDTree would enter at a branch
+//     (KDTree.cpp:169-201), so descending from the root towards a given leaf tells whether
+//     that leaf is visited; a refused child excludes its whole range of leaf ids at once.
+// first_visited_position() therefore returns the shape's position in the reference's visit
+// order (its leaf_refs index in the first visited leaf holding it), or none.  Exact depth
+// ties between different shapes are resolved with these positions, as the strict `<` of
+// KDTree.cpp:212 does.
+constexpr uint32_t kNoPosition = 0xffffffffu;
+
+RTX_DEV void branch_predicate(const Branch* __restrict__ b, d3 o, d3 d, d3 inv, bool& go_lesser, bool& go_greater)
+{
+    double tmin, tmax;
+    // callers have finite 1/direction, where this equals the select-based slab test
+    slab_finite(reinterpret_cast<const PrimBox*>(b->bmin), o, inv, tmin, tmax);
+    go_lesser = go_greater = false;
+    if (tmin < tmax && tmax >= 0.0) {
+        int axis = b->axis;
+        double value = b->value;
+        double oa = pick(o, axis), da = pick(d, axis);
+        double enter = oa + (da * tmin);
+        double exit_ = oa + (da * tmax);
+        if (enter <= value) { go_lesser = true; go_greater = !(exit_ < value); }
+        else { go_greater = true; go_lesser = !(exit_ > value); }
+    }
+}
+
+// index of the first entry >= key in the sorted range ids[lo, hi)
+RTX_DEV uint32_t lower_bound_u32(const uint32_t* __restrict__ ids, uint32_t lo, uint32_t hi, uint32_t key)
+{
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (ids[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool COUNT>
+RTX_DEV uint32_t first_visited_position(const DScene& s, uint32_t shape, d3 o, d3 d, d3 inv, Work<COUNT>& w)
+{
+    const uint32_t first = s.prim_leaf_first[shape], end = s.prim_leaf_first[shape + 1];
+    uint32_t i = first;
+    while (i < end) {
+        uint32_t target = s.prim_leaf_ids[i];
+        int32_t node = s.root;
+        uint32_t skip_to;
+        for (;;) {
+            if (node < 0) return s.prim_leaf_pos[i];           // reached the leaf `target`: it is visited
+            const Branch* b = s.branches + node;
+            bool gl, gg;
+            branch_predicate(b, o, d, inv, gl, gg);
+            if constexpr (COUNT) w.branch++;
+            if (target < b->leaf_mid) {
+                if (gl) node = b->lesser; else { skip_to = b->leaf_mid; break; }
+            } else {
+                if (gg) node = b->greater; else { skip_to = b->leaf_hi; break; }
+            }
+        }
+        i = lower_bound_u32(s.prim_leaf_ids, i + 1, end, skip_to);
+    }
+    return kNoPosition;
+}
+
+// Cheap existence proof: follow the KD tree towards the leaf that contains the point p
+// (normally the hit point) as long as the reference would go that way, then look the shape
+// up in that leaf.  A `false` only means "not shown this way".
+template <bool COUNT>
+RTX_DEV bool member_through_point(const DScene& s, uint32_t shape, d3 p, d3 o, d3 d, d3 inv, Work<COUNT>& w)
+{
+    int32_t node = s.root;
+    while (node >= 0) {
+        const Branch* b = s.branches + node;
+        bool gl, gg;
+        branch_predicate(b, o, d, inv, gl, gg);
+        if constexpr (COUNT) w.branch++;
+        bool lesser_side = pick(p, b->axis) <= b->value;
+        if (lesser_side ? gl : gg) node = lesser_side ? b->lesser : b->greater;
+        else if (lesser_side ? gg : gl) node = lesser_side ? b->greater : b->lesser;
+        else return false;
+    }
+    uint32_t leaf = (uint32_t)~node;
+    const uint32_t first = s.prim_leaf_first[shape], end = s.prim_leaf_first[shape + 1];
+    uint32_t at = lower_bound_u32(s.prim_leaf_ids, first, end, leaf);
+    if constexpr (COUNT) w.leaf++;
+    return at < end && s.prim_leaf_ids[at] == leaf;
+}
+
+template <bool COUNT, bool ANYHIT>
+RTX_DEV void trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* stack, int32_t& best_prim,
+                            double& best_depth, Work<COUNT>& w)
+{
+    best_prim = -1;
+    best_depth = kInf;
+    if (s.bvh_root == kBvhEmpty) return;
+    uint32_t best_shape = 0, best_pos = kNoPosition;
+    d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    const double abs_margin = 1e-9 * (s.scene_scale + __builtin_fmax(fabs(o.x), __builtin_fmax(fabs(o.y), fabs(o.z))));
+    double bound2 = kInf;
+    if constexpr (ANYHIT) { double bd = limit * (1.0 + 1e-7) + abs_margin; bound2 = bd * bd; }
+    int sp = 0;
+    int32_t node = s.bvh_root;
+    for (;;) {
+        if (node >= 0) {
+            const BvhNode* n = s.bvh_nodes + node;
+            double lmin, lmax, rmin, rmax;
+            slab_finite(&n->lbox, o, inv, lmin, lmax);
+            slab_finite(&n->rbox, o, inv, rmin, rmax);
+            if constexpr (COUNT) w.content += 2;
+            bool hl = lmin <= lmax && lmax >= 0.0 && !(box_distance2(&n->lbox, o) > bound2);
+            bool hr = rmin <= rmax && rmax >= 0.0 && !(box_distance2(&n->rbox, o) > bound2);
+            int32_t left = n->left, right = n->right;
+            if (hl && hr) {
+                bool left_first = lmin <= rmin;
+                stack[sp * kBlock] = left_first ? right : left;
+                ++sp;
+                node = left_first ? left : right;
+                continue;
+            }
+            if (hl) { node = left; continue; }
+            if (hr) { node = right; continue; }
+        } else {
+            uint2 fc = s.bvh_leaves[(uint32_t)~node];
+            for (uint32_t k = 0; k < fc.y; ++k) {
+                uint32_t shape = s.bvh_prims[fc.x + k];
+                double tmin, tmax;
+                slab_finite(s.prim_box + shape, o, inv, tmin, tmax);
+                if constexpr (COUNT) w.aabb++;
+                if (!(tmin <= tmax && tmax >= 0.0)) continue;
+                uint32_t info = s.prim_info[shape];
+                uint32_t type = info & 3u, idx = info >> 2;
+                double depth = kInf;
+                uint32_t rp = shape;
+                bool ok;
+                if (type == RTX_PRIM_TRIANGLE) {
+                    if constexpr (COUNT) w.tri++;
+                    ok = triangle_depth(s.tri_pos + 9 * (size_t)idx, o, d, depth);
+                } else if (type == RTX_PRIM_SPHERE) {
+                    if constexpr (COUNT) w.sph++;
+                    ok = sphere_t(ld3(s.sph_center + 3 * (size_t)idx), s.sph_r2[idx], o, d, depth);
+                } else {
+                    if constexpr (COUNT) w.sph += 2;
+                    ok = biconvex_depth(s, idx, o, d, depth, rp);
+                }
+                if (!ok) continue;
+                if constexpr (ANYHIT) {
+                    if (depth <= limit &&
+                        (member_through_point<COUNT>(s, shape, o + (d * depth), o, d, inv, w) ||
+                         first_visited_position<COUNT>(s, shape, o, d, inv, w) != kNoPosition)) {
+                        best_depth = depth; best_prim = (int32_t)rp;
+                        return;
+                    }
+                } else if (depth < best_depth) {
+                    if (member_through_point<COUNT>(s, shape, o + (d * depth), o, d, inv, w) ||
+                        first_visited_position<COUNT>(s, shape, o, d, inv, w) != kNoPosition) {
+                        if constexpr (COUNT) w.accepted++;
+                        best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; best_pos = kNoPosition;
+                        double bd = best_depth * (1.0 + 1e-7) + abs_margin;
+                        bound2 = bd * bd;
+                    }
+                } else if (depth == best_depth && (int32_t)rp != best_prim) {
+                    // exact tie between two primitives: the reference keeps the one it met first
+                    if (best_pos == kNoPosition) best_pos = first_visited_position<COUNT>(s, best_shape, o, d, inv, w);
+                    uint32_t pos = first_visited_position<COUNT>(s, shape, o, d, inv, w);
+                    if (pos < best_pos) { best_prim = (int32_t)rp; best_shape = shape; best_pos = pos; }
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        node = stack[sp * kBlock];
+    }
+    if constexpr (ANYHIT) { best_depth = kInf; best_prim = -1; }
+}
+
 RTX_DEV bool culling_is_exact(d3 o, d3 d)
 {
     d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
@@ -315,7 +496,10 @@ RTX_DEV void add_counters(Counters g, const Work<true>& w)
 }
 RTX_DEV void add_counters(Counters, const Work<false>&) {}
 
-// shootRay for caller-supplied rays (rtx_trace_closest)
+// shootRay for caller-supplied rays (rtx_trace_closest).  MODE 0 walks in the reference's
+// order and reports leaf sequences; MODE 1 (culled KD walk) and 3 (BVH) are the render
+// path's walks, for which the leaf outputs describe nothing the reference does.
+template <int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_trace_api(DScene s, const double* __restrict__ origin, const double* __restrict__ direction, uint32_t n,
             uint32_t linear, int32_t* prim, double* depth, double* position, double* normal, double* uv, double* bary,
@@ -328,8 +512,13 @@ k_trace_api(DScene s, const double* __restrict__ origin, const double* __restric
     Ray r = make_ray(ld3(origin + 3 * (size_t)i), ld3(direction + 3 * (size_t)i));
     Work<true> w;
     int32_t bp; double bd;
-    trace_lane<true>(s, r.o, r.d, linear != 0, stack + threadIdx.x, bp, bd, w,
-                     leaf_seq ? leaf_seq + (size_t)i * leaf_seq_cap : nullptr, leaf_seq_cap);
+    if (MODE == 0 || linear != 0 || !culling_is_exact(r.o, r.d))
+        trace_lane<true>(s, r.o, r.d, linear != 0, stack + threadIdx.x, bp, bd, w,
+                         leaf_seq ? leaf_seq + (size_t)i * leaf_seq_cap : nullptr, leaf_seq_cap);
+    else if (MODE == 1)
+        trace_lane_culled<true, false>(s, r.o, r.d, kInf, stack + threadIdx.x, bp, bd, w);
+    else
+        trace_lane_bvh<true, false>(s, r.o, r.d, kInf, stack + threadIdx.x, bp, bd, w);
     prim[i] = bp;
     depth[i] = bd;
     Hit h;
@@ -348,8 +537,8 @@ k_trace_api(DScene s, const double* __restrict__ origin, const double* __restric
 }
 
 // shootRay for a queue: reads (o, d), writes (hit_prim, hit_depth).
-// MODE 0: the reference's walk order; 1: culled walk, closest hit; 2: culled walk, any hit
-// with depth <= limit[i] (depth = +inf when there is none).
+// MODE 0: the reference's walk order; 1 / 2: culled KD walk, closest hit / any hit with
+// depth <= limit[i] (depth = +inf when there is none); 3 / 4: the same through the BVH.
 template <bool COUNT, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
@@ -367,8 +556,12 @@ k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__
         trace_lane<COUNT>(s, o, d, linear != 0, stack + threadIdx.x, bp, bd, w, nullptr, 0);
     else if (MODE == 1)
         trace_lane_culled<COUNT, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w);
-    else
+    else if (MODE == 2)
         trace_lane_culled<COUNT, true>(s, o, d, limit[i], stack + threadIdx.x, bp, bd, w);
+    else if (MODE == 3)
+        trace_lane_bvh<COUNT, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w);
+    else
+        trace_lane_bvh<COUNT, true>(s, o, d, limit[i], stack + threadIdx.x, bp, bd, w);
     if (hit_prim) hit_prim[i] = bp;
     hit_depth[i] = bd;
     add_counters(g, w);

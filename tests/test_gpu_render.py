@@ -89,15 +89,20 @@ def test_culled_walk_gives_identical_images(gpu, name, make, kw):
     kw = dict(kw)
     flags = kw.pop("flags", 0)
     fast = scenes.render_desc(144, 96, camera=cam, seed=9, flags=flags | abi.FLAG_COUNTERS, **kw)
+    mid = scenes.render_desc(144, 96, camera=cam, seed=9, flags=flags | abi.FLAG_COUNTERS | abi.FLAG_KD_CULLED, **kw)
     slow = scenes.render_desc(144, 96, camera=cam, seed=9,
                               flags=flags | abi.FLAG_COUNTERS | abi.FLAG_REFERENCE_ORDER, **kw)
     with gpu.DeviceScene(desc) as ds:
-        a, sa = ds.render(fast)
-        b, sb = ds.render(slow)
+        a, sa = ds.render(fast)         # BVH candidates + membership verification (default)
+        m, sm = ds.render(mid)          # reference KD tree walked with culling
+        b, sb = ds.render(slow)         # reference order, nothing skipped
     assert np.array_equal(a, b)
+    assert np.array_equal(m, b)
     _same_ray_counts(sa, sb)
+    _same_ray_counts(sm, sb)
     assert sb.content_tests == 0
     if desc.n_branches > 100:
+        assert sm.aabb_tests + sm.content_tests + sm.branch_visits < sb.aabb_tests + sb.branch_visits
         assert sa.aabb_tests + sa.content_tests + sa.branch_visits < sb.aabb_tests + sb.branch_visits
 
 

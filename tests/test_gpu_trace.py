@@ -110,3 +110,41 @@ def test_malformed_scene_is_rejected(gpu):
     with pytest.raises(gpu.RtxError) as e:
         gpu.DeviceScene(bad)
     assert e.value.code == abi.RTX_ERR_INVALID
+
+
+def _scenes_for_walks():
+    yield "live", lambda: scenes.live_scene()[0], 0.7, 30.0
+    yield "mesh", lambda: scenes.mesh_scene(slices=100, stacks=50)[0], 0.0, 8.0
+    yield "lens", lambda: scenes.lens_scene()[0], 0.0, 8.0
+    yield "whitted", lambda: scenes.whitted_scene()[0], 0.0, 8.0
+
+
+@pytest.mark.parametrize("name,make,t,box", list(_scenes_for_walks()), ids=[c[0] for c in _scenes_for_walks()])
+@pytest.mark.parametrize("walk", ["bvh", "kd_culled"])
+def test_render_walks_find_the_reference_hit(gpu, name, make, t, box, walk):
+    """The render path's walks (BVH candidates + membership verification; culled KD walk)
+    must report exactly the hit the reference-order walk reports: same primitive id (ties
+    included), same depth bits, same hit record -- on incoherent random rays, rays starting
+    on surfaces, and axis-parallel rays (which take the reference walk internally)."""
+    scene = make()
+    desc = scene.frame(t)
+    rng = np.random.default_rng(5)
+    o, d = _random_rays(rng, 60000, box=box)
+    # rays that start on geometry (like shadow and bounce rays do)
+    with gpu.DeviceScene(desc) as ds:
+        first = ds.trace_closest(o, d)
+        hit = first["prim"] >= 0
+        o2 = first["position"][hit] + 1e-3 * first["normal"][hit]
+        d2 = rng.normal(size=o2.shape)
+        axis = np.eye(3)[rng.integers(0, 3, 2000)] * rng.choice([-1.0, 1.0], size=(2000, 1))
+        o3 = rng.uniform(-box, box, size=(2000, 3))
+        oo = np.vstack([o, o2, o3])
+        dd = np.vstack([d, d2, axis])
+        flags = abi.FLAG_RENDER_WALK | (abi.FLAG_KD_CULLED if walk == "kd_culled" else 0)
+        got = ds.trace_closest(oo, dd, flags=flags)
+    want = orc.trace_closest(desc, oo, dd)
+    for key in ("prim", "depth", "position", "normal", "bary"):
+        g, w = got[key], want[key]
+        same = (g == w) | ((g != g) & (w != w)) if g.dtype.kind == "f" else g == w
+        assert same.all(), f"{key}: {np.count_nonzero(~same)} of {same.size} differ"
+    assert (want["prim"] >= 0).mean() > 0.05
