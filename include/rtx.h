@@ -236,7 +236,9 @@ typedef struct rtx_stats {
     uint64_t triangle_tests;        /* Triangle::rayHit calls                    */
     uint64_t sphere_tests;          /* Sphere::rayHit calls (2 per lens)         */
     uint64_t hits_accepted;         /* closer-hit replacements                   */
-    uint64_t content_tests;         /* content-box tests of the culled walk      */
+    uint64_t content_tests;         /* content-box / BVH child-box tests         */
+    uint64_t fallback_rays;         /* rays the fast walk could not certify and
+                                       re-traced in reference order               */
     /* device time per stage in milliseconds (HIP events on the library stream);
        ms_total always, the per-stage sums with RTX_FLAG_STAGE_TIMES */
     double ms_generate;

@@ -120,7 +120,7 @@ class Stats(C.Structure):
         ("rays_primary", C.c_uint64), ("rays_secondary", C.c_uint64), ("rays_shadow", C.c_uint64),
         ("branch_visits", C.c_uint64), ("leaf_visits", C.c_uint64), ("aabb_tests", C.c_uint64),
         ("triangle_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("hits_accepted", C.c_uint64),
-        ("content_tests", C.c_uint64),
+        ("content_tests", C.c_uint64), ("fallback_rays", C.c_uint64),
         ("ms_generate", C.c_double), ("ms_traverse", C.c_double), ("ms_shade", C.c_double),
         ("ms_shadow", C.c_double), ("ms_resolve", C.c_double), ("ms_total", C.c_double),
         ("traverse_launches", C.c_uint32), ("max_queue", C.c_uint32),

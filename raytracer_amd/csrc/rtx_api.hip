@@ -529,8 +529,8 @@ int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* directi
 
 // limit == nullptr: closest hit; otherwise any hit with depth <= limit[i] (shadow rays)
 static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const double* oz, const double* dx,
-                        const double* dy, const double* dz, const double* limit, uint32_t n, uint32_t flags,
-                        int32_t* hit_prim, double* hit_depth, bool count)
+                        const double* dy, const double* dz, const double* limit, uint32_t n, const uint32_t* n_device,
+                        uint32_t flags, int32_t* hit_prim, double* hit_depth, bool count)
 {
     uint32_t linear = (flags & RTX_FLAG_LINEAR_SCAN) ? 1u : 0u;
     int mode;
@@ -542,7 +542,7 @@ static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const
     dim3 grid = grid_for(n), block(kBlock);
 #define RTX_LAUNCH_TRACE(COUNT, MODE)                                                                                  \
     hipLaunchKernelGGL((k_trace_pool<COUNT, MODE>), grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
-                       linear, hit_prim, hit_depth, g)
+                       n_device, linear, hit_prim, hit_depth, g)
 #define RTX_LAUNCH_MODES(COUNT)                                                                   \
     switch (mode) {                                                                               \
     case 0: RTX_LAUNCH_TRACE(COUNT, 0); break;                                                    \
@@ -576,9 +576,8 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     p.d = *rd;
     p.d.pixel_multisample_n = n;
     p.n = n;
-    p.blocks_w = (rd->tile_w + 7) / 8;
-    uint32_t blocks_h = (rd->tile_h + 7) / 8;
-    uint64_t padded_pixels = (uint64_t)p.blocks_w * blocks_h * 64;
+    const uint64_t padded_pixels = (uint64_t)rd->tile_w * rd->tile_h;     // every index is a pixel
+    if (padded_pixels * n * n > 0xffffffffull) return fail(RTX_ERR_LIMIT, "more than 2^32 samples per pass in one tile");
     uint32_t nn = n * n;
     uint32_t shadow_per_hit = 0;
     if (whitted && !(rd->flags & RTX_FLAG_NO_LIGHTING)) {
@@ -626,12 +625,10 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
             HIP_TRY(hipMemsetAsync(w.sample, 0, slots * 3 * sizeof(double), st));
             HIP_TRY(hipMemsetAsync(w.counts, 0, 4 * sizeof(uint32_t), st));
             timer.begin();
-            hipLaunchKernelGGL(k_generate, grid_for(slots), dim3(kBlock), 0, st, p, w.q[0], w.counts + 2);
+            hipLaunchKernelGGL(k_generate, grid_for(slots), dim3(kBlock), 0, st, p, w.q[0]);
             HIP_TRY(hipGetLastError());
             timer.end(&local.ms_generate);
-            uint32_t count = 0;
-            rc = read_count(sc, 2, &count);
-            if (rc != RTX_OK) return rc;
+            uint32_t count = (uint32_t)slots;        // one camera ray per sample slot
             int cur = 0;
             uint32_t level = 0;
             while (count > 0) {
@@ -641,7 +638,8 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 local.max_queue = std::max(local.max_queue, count);
                 if (level == 0) local.rays_primary += count; else local.rays_secondary += count;
                 timer.begin();
-                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, count, rd->flags, q.hit_prim, q.hit_depth, count_work);
+                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, count, nullptr, rd->flags, q.hit_prim, q.hit_depth,
+                                  count_work);
                 if (rc != RTX_OK) return rc;
                 timer.end(&local.ms_traverse);
                 local.traverse_launches++;
@@ -657,15 +655,14 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                                        w.counts + 1, w.shadow_index, w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
-                    uint32_t nshadow = 0;
-                    rc = read_count(sc, 1, &nshadow);
-                    if (rc != RTX_OK) return rc;
-                    if (nshadow > w.shadow_capacity) return fail(RTX_ERR_LIMIT, "shadow queue overflow");
-                    if (nshadow > 0) {
-                        local.rays_shadow += nshadow;
+                    // the shadow queue's length stays on the device: the launch is sized for the
+                    // most it can be and reads the real length itself
+                    uint64_t shadow_max = (uint64_t)count * shadow_per_hit;
+                    if (shadow_max > w.shadow_capacity) return fail(RTX_ERR_LIMIT, "shadow queue overflow");
+                    if (shadow_max > 0) {
                         timer.begin();
-                        rc = launch_trace(sc, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, w.sq.limit, nshadow, rd->flags, nullptr,
-                                          w.sq.hit_depth, count_work);
+                        rc = launch_trace(sc, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, w.sq.limit, (uint32_t)shadow_max,
+                                          w.counts + 1, rd->flags, nullptr, w.sq.hit_depth, count_work);
                         if (rc != RTX_OK) return rc;
                         timer.end(&local.ms_shadow);
                         local.traverse_launches++;
@@ -676,8 +673,11 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                 }
-                rc = read_count(sc, 0, &count);
-                if (rc != RTX_OK) return rc;
+                // one readback per level: next queue length and (Whitted) shadow rays traced
+                HIP_TRY(hipMemcpyAsync(w.host_counts, w.counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                count = w.host_counts[0];
+                local.rays_shadow += w.host_counts[1];
                 cur ^= 1;
                 ++level;
             }
@@ -701,7 +701,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         if (count_work) {
             local.branch_visits = w.host_work[0]; local.leaf_visits = w.host_work[1]; local.aabb_tests = w.host_work[2];
             local.triangle_tests = w.host_work[3]; local.sphere_tests = w.host_work[4]; local.hits_accepted = w.host_work[5];
-            local.content_tests = w.host_work[6];
+            local.content_tests = w.host_work[6]; local.fallback_rays = w.host_work[7];
         }
         *stats = local;
     }

@@ -70,7 +70,8 @@ RTX_DEV uint32_t wave_reserve(bool pred, uint32_t* counter, uint32_t per_item = 
 template <bool COUNT>
 struct Work {
     uint32_t branch = 0, leaf = 0, aabb = 0, tri = 0, sph = 0, accepted = 0;
-    uint32_t content = 0;           // content-box tests of the culled walk
+    uint32_t content = 0;           // content-box tests of the culled walk / BVH child-box tests
+    uint32_t fallback = 0;          // rays re-traced in reference order
     uint32_t leaf_count = 0;
     unsigned long long leaf_hash = 14695981039346656037ull;
 };
@@ -393,21 +394,29 @@ RTX_DEV bool member_through_point(const DScene& s, uint32_t shape, d3 p, d3 o, d
     return at < end && s.prim_leaf_ids[at] == leaf;
 }
 
+// Optimistic form: the BVH walk treats every geometric candidate as genuine, so its loop
+// holds no long divergent section; the winner is verified once, after the loop, when the
+// lanes of the wave have reconverged.  Returns false when the optimistic answer cannot be
+// certified -- the winner is in no visited leaf, or two different primitives tie exactly
+// at the winning depth (their visit order would decide) -- and the caller then runs the
+// reference-order walk for that ray.  Both are rare.
 template <bool COUNT, bool ANYHIT>
-RTX_DEV void trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* stack, int32_t& best_prim,
+RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* stack, int32_t& best_prim,
                             double& best_depth, Work<COUNT>& w)
 {
     best_prim = -1;
     best_depth = kInf;
-    if (s.bvh_root == kBvhEmpty) return;
-    uint32_t best_shape = 0, best_pos = kNoPosition;
+    if (s.bvh_root == kBvhEmpty) return true;
+    uint32_t best_shape = 0;
+    bool tie = false;
     d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     const double abs_margin = 1e-9 * (s.scene_scale + __builtin_fmax(fabs(o.x), __builtin_fmax(fabs(o.y), fabs(o.z))));
     double bound2 = kInf;
     if constexpr (ANYHIT) { double bd = limit * (1.0 + 1e-7) + abs_margin; bound2 = bd * bd; }
     int sp = 0;
     int32_t node = s.bvh_root;
-    for (;;) {
+    bool done = false;
+    while (!done) {
         if (node >= 0) {
             const BvhNode* n = s.bvh_nodes + node;
             double lmin, lmax, rmin, rmax;
@@ -451,33 +460,25 @@ RTX_DEV void trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 }
                 if (!ok) continue;
                 if constexpr (ANYHIT) {
-                    if (depth <= limit &&
-                        (member_through_point<COUNT>(s, shape, o + (d * depth), o, d, inv, w) ||
-                         first_visited_position<COUNT>(s, shape, o, d, inv, w) != kNoPosition)) {
-                        best_depth = depth; best_prim = (int32_t)rp;
-                        return;
-                    }
+                    if (depth <= limit) { best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; done = true; break; }
                 } else if (depth < best_depth) {
-                    if (member_through_point<COUNT>(s, shape, o + (d * depth), o, d, inv, w) ||
-                        first_visited_position<COUNT>(s, shape, o, d, inv, w) != kNoPosition) {
-                        if constexpr (COUNT) w.accepted++;
-                        best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; best_pos = kNoPosition;
-                        double bd = best_depth * (1.0 + 1e-7) + abs_margin;
-                        bound2 = bd * bd;
-                    }
+                    if constexpr (COUNT) w.accepted++;
+                    best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; tie = false;
+                    double bd = best_depth * (1.0 + 1e-7) + abs_margin;
+                    bound2 = bd * bd;
                 } else if (depth == best_depth && (int32_t)rp != best_prim) {
-                    // exact tie between two primitives: the reference keeps the one it met first
-                    if (best_pos == kNoPosition) best_pos = first_visited_position<COUNT>(s, best_shape, o, d, inv, w);
-                    uint32_t pos = first_visited_position<COUNT>(s, shape, o, d, inv, w);
-                    if (pos < best_pos) { best_prim = (int32_t)rp; best_shape = shape; best_pos = pos; }
+                    tie = true;
                 }
             }
         }
-        if (sp == 0) break;
+        if (done || sp == 0) break;
         --sp;
         node = stack[sp * kBlock];
     }
-    if constexpr (ANYHIT) { best_depth = kInf; best_prim = -1; }
+    if (best_prim < 0) return true;                 // no geometric candidate at all: the reference finds none either
+    if (tie) return false;
+    return member_through_point<COUNT>(s, best_shape, o + (d * best_depth), o, d, inv, w) ||
+           first_visited_position<COUNT>(s, best_shape, o, d, inv, w) != kNoPosition;
 }
 
 RTX_DEV bool culling_is_exact(d3 o, d3 d)
@@ -493,6 +494,7 @@ RTX_DEV void add_counters(Counters g, const Work<true>& w)
     atomicAdd(g.c + 2, (unsigned long long)w.aabb); atomicAdd(g.c + 3, (unsigned long long)w.tri);
     atomicAdd(g.c + 4, (unsigned long long)w.sph); atomicAdd(g.c + 5, (unsigned long long)w.accepted);
     atomicAdd(g.c + 6, (unsigned long long)w.content);
+    atomicAdd(g.c + 7, (unsigned long long)w.fallback);
 }
 RTX_DEV void add_counters(Counters, const Work<false>&) {}
 
@@ -511,14 +513,15 @@ k_trace_api(DScene s, const double* __restrict__ origin, const double* __restric
     if (i >= n) return;
     Ray r = make_ray(ld3(origin + 3 * (size_t)i), ld3(direction + 3 * (size_t)i));
     Work<true> w;
-    int32_t bp; double bd;
-    if (MODE == 0 || linear != 0 || !culling_is_exact(r.o, r.d))
+    int32_t bp = -1; double bd = kInf;
+    bool settled = false;
+    if (MODE != 0 && linear == 0 && culling_is_exact(r.o, r.d)) {
+        if (MODE == 1) { trace_lane_culled<true, false>(s, r.o, r.d, kInf, stack + threadIdx.x, bp, bd, w); settled = true; }
+        else settled = trace_lane_bvh<true, false>(s, r.o, r.d, kInf, stack + threadIdx.x, bp, bd, w);
+    }
+    if (!settled)
         trace_lane<true>(s, r.o, r.d, linear != 0, stack + threadIdx.x, bp, bd, w,
                          leaf_seq ? leaf_seq + (size_t)i * leaf_seq_cap : nullptr, leaf_seq_cap);
-    else if (MODE == 1)
-        trace_lane_culled<true, false>(s, r.o, r.d, kInf, stack + threadIdx.x, bp, bd, w);
-    else
-        trace_lane_bvh<true, false>(s, r.o, r.d, kInf, stack + threadIdx.x, bp, bd, w);
     prim[i] = bp;
     depth[i] = bd;
     Hit h;
@@ -543,39 +546,69 @@ template <bool COUNT, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
              const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
-             const double* __restrict__ limit, uint32_t n, uint32_t linear, int32_t* hit_prim, double* hit_depth,
-             Counters g)
+             const double* __restrict__ limit, uint32_t n, const uint32_t* __restrict__ n_device, uint32_t linear,
+             int32_t* hit_prim, double* hit_depth, Counters g)
 {
     __shared__ int32_t stack[kStack * kBlock];
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    // the grid is sized for n; when the real queue length is only known on the device
+    // (n_device), the surplus workgroups leave here
+    if (n_device) n = min(n, *n_device);
     if (i >= n) return;
     d3 o = mk(ox[i], oy[i], oz[i]), d = mk(dx[i], dy[i], dz[i]);
     Work<COUNT> w;
-    int32_t bp; double bd;
-    if (MODE == 0 || linear != 0 || !culling_is_exact(o, d))
+    int32_t bp = -1; double bd = kInf;
+    bool settled = false;
+    if (MODE != 0 && linear == 0 && culling_is_exact(o, d)) {
+        if (MODE == 1) { trace_lane_culled<COUNT, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w); settled = true; }
+        else if (MODE == 2) { trace_lane_culled<COUNT, true>(s, o, d, limit[i], stack + threadIdx.x, bp, bd, w); settled = true; }
+        else if (MODE == 3) settled = trace_lane_bvh<COUNT, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w);
+        else settled = trace_lane_bvh<COUNT, true>(s, o, d, limit[i], stack + threadIdx.x, bp, bd, w);
+    }
+    if (!settled) {
+        if constexpr (COUNT) w.fallback++;
         trace_lane<COUNT>(s, o, d, linear != 0, stack + threadIdx.x, bp, bd, w, nullptr, 0);
-    else if (MODE == 1)
-        trace_lane_culled<COUNT, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w);
-    else if (MODE == 2)
-        trace_lane_culled<COUNT, true>(s, o, d, limit[i], stack + threadIdx.x, bp, bd, w);
-    else if (MODE == 3)
-        trace_lane_bvh<COUNT, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w);
-    else
-        trace_lane_bvh<COUNT, true>(s, o, d, limit[i], stack + threadIdx.x, bp, bd, w);
+    }
     if (hit_prim) hit_prim[i] = bp;
     hit_depth[i] = bd;
     add_counters(g, w);
 }
 
 // ---- pixel <-> slot mapping ------------------------------------------------------------------
-// Padded pixel index t walks the tile in 8x8 blocks so that a wave's 64 rays are neighbours.
-RTX_DEV bool pixel_of(const RenderParams& p, uint32_t t, uint32_t& x, uint32_t& y)
+// Pixel index t in [0, tile_w*tile_h) walks the tile in bands of 8 rows and, inside a band,
+// in blocks of 8 columns (the last band / block may be narrower), so that the 64 lanes of a
+// wave are neighbouring pixels.  Every t is a pixel: nothing needs compacting away.
+RTX_DEV void pixel_of(const RenderParams& p, uint32_t t, uint32_t& x, uint32_t& y)
 {
-    uint32_t block = t >> 6, inb = t & 63u;
-    uint32_t bx = block % p.blocks_w, by = block / p.blocks_w;
-    uint32_t lx = bx * 8 + (inb & 7u), ly = by * 8 + (inb >> 3);
-    x = p.d.tile_x0 + lx; y = p.d.tile_y0 + ly;
-    return lx < p.d.tile_w && ly < p.d.tile_h;
+    const uint32_t W = p.d.tile_w, H = p.d.tile_h;
+    uint32_t band = t / (8u * W);
+    uint32_t r = t - band * 8u * W;
+    uint32_t hb = min(8u, H - 8u * band);
+    uint32_t bx = r / (8u * hb);
+    uint32_t r2 = r - bx * 8u * hb;
+    uint32_t wb = min(8u, W - 8u * bx);
+    uint32_t ly = r2 / wb, lx = r2 - ly * wb;
+    x = p.d.tile_x0 + bx * 8u + lx;
+    y = p.d.tile_y0 + band * 8u + ly;
+}
+
+// Block-wide reservation of queue space: one atomic per workgroup.  Every thread of the
+// workgroup must call it.  `lds` is kBlock/64 + 1 words of scratch.
+RTX_DEV uint32_t block_reserve(bool pred, uint32_t* counter, uint32_t per_item, uint32_t* lds)
+{
+    unsigned long long mask = __ballot(pred);
+    uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    uint32_t wave = threadIdx.x >> 6;
+    __syncthreads();                                    // lds may still be read from a previous call
+    if ((threadIdx.x & 63u) == 0) lds[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (uint32_t k = 0; k < kBlock / 64; ++k) { uint32_t c = lds[k]; lds[k] = sum; sum += c; }
+        lds[kBlock / 64] = sum ? atomicAdd(counter, sum * per_item) : 0u;
+    }
+    __syncthreads();
+    return lds[kBlock / 64] + (lds[wave] + prefix) * per_item;
 }
 
 RTX_DEV void push_ray(const RayQueue& q, uint32_t j, const Ray& r, d3 w, double ior, uint32_t slot, uint32_t layer,
@@ -589,33 +622,27 @@ RTX_DEV void push_ray(const RayQueue& q, uint32_t j, const Ray& r, d3 w, double 
 
 // camera rays of one chunk (Raytracer.cpp:676-700); one thread per sample slot
 __global__ void __launch_bounds__(kBlock)
-k_generate(RenderParams p, RayQueue q, uint32_t* count)
+k_generate(RenderParams p, RayQueue q)
 {
     uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     uint32_t nn = p.n * p.n;
     uint32_t total = p.chunk_pixels * nn;
-    bool valid = false;
-    Ray ray;
-    if (slot < total) {
-        uint32_t t = p.chunk_t0 + slot / nn, sub = slot % nn;
-        uint32_t x, y;
-        if (pixel_of(p, t, x, y)) {
-            valid = true;
-            uint32_t sx = sub / p.n + 1, sy = sub % p.n + 1;
-            const rtx_camera& c = p.d.camera;
-            double nx = ((double)x / (double)p.d.width) - 0.5;
-            double ny = ((double)y / (double)p.d.height) - 0.5;
-            d3 eye = ld3(c.eye);
-            d3 on_screen = (((ld3(c.right) * nx) + (ld3(c.up) * ny)) + eye) + (ld3(c.forward) * c.focal);
-            double cx = 1.0 / ((double)p.d.width - 1.0), cy = 1.0 / ((double)p.d.height - 1.0);
-            double offx = (double)sx * (cx / (double)(p.n + 1));
-            double offy = (double)sy * (cy / (double)(p.n + 1));
-            d3 v = normalize3((on_screen + mk(offx, offy, 0.0)) - eye);
-            ray = make_ray(eye, v);
-        }
-    }
-    uint32_t j = wave_reserve(valid, count);
-    if (valid && j < p.queue_cap) push_ray(q, j, ray, mk(1.0, 1.0, 1.0), 1.0, slot, 0u, 0u, 0u);
+    if (slot >= total || slot >= p.queue_cap) return;
+    uint32_t t = p.chunk_t0 + slot / nn, sub = slot % nn;
+    uint32_t x, y;
+    pixel_of(p, t, x, y);
+    uint32_t sx = sub / p.n + 1, sy = sub % p.n + 1;
+    const rtx_camera& c = p.d.camera;
+    double nx = ((double)x / (double)p.d.width) - 0.5;
+    double ny = ((double)y / (double)p.d.height) - 0.5;
+    d3 eye = ld3(c.eye);
+    d3 on_screen = (((ld3(c.right) * nx) + (ld3(c.up) * ny)) + eye) + (ld3(c.forward) * c.focal);
+    double cx = 1.0 / ((double)p.d.width - 1.0), cy = 1.0 / ((double)p.d.height - 1.0);
+    double offx = (double)sx * (cx / (double)(p.n + 1));
+    double offy = (double)sy * (cy / (double)(p.n + 1));
+    d3 v = normalize3((on_screen + mk(offx, offy, 0.0)) - eye);
+    // ray i of the first queue is sample slot i
+    push_ray(q, slot, make_ray(eye, v), mk(1.0, 1.0, 1.0), 1.0, slot, 0u, 0u, 0u);
 }
 
 RTX_DEV void sample_add(double* sample, uint32_t slot, d3 v)
@@ -722,7 +749,8 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, RayQueue next, ui
             }
         }
     }
-    uint32_t j = wave_reserve(spawn, next_count);
+    __shared__ uint32_t reserve_lds[kBlock / 64 + 1];
+    uint32_t j = block_reserve(spawn, next_count, 1, reserve_lds);
     if (spawn && j < p.queue_cap) push_ray(next, j, child, cw, cior, slot, layer + 1, cbranch, ccounter);
 }
 
@@ -743,7 +771,8 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
         }
     }
     bool emit = hit && p.shadow_per_hit > 0 && !(p.d.flags & RTX_FLAG_NO_LIGHTING);
-    uint32_t base = wave_reserve(emit, shadow_count, p.shadow_per_hit);
+    __shared__ uint32_t reserve_lds[kBlock / 64 + 1];
+    uint32_t base = block_reserve(emit, shadow_count, p.shadow_per_hit, reserve_lds);
     if (i < n) shadow_base[i] = base;
     if (emit && (unsigned long long)base + p.shadow_per_hit <= p.shadow_cap) {
         d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
@@ -838,9 +867,10 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
         }
         sample_add(sample, slot, w * (local * wl));
     }
-    uint32_t jt = wave_reserve(spawn_t, next_count);
+    __shared__ uint32_t reserve_lds[kBlock / 64 + 1];
+    uint32_t jt = block_reserve(spawn_t, next_count, 1, reserve_lds);
     if (spawn_t && jt < p.queue_cap) push_ray(next, jt, child_t, wt, ni, slot, layer + 1, branch, counter);
-    uint32_t jr = wave_reserve(spawn_r, next_count);
+    uint32_t jr = block_reserve(spawn_r, next_count, 1, reserve_lds);
     if (spawn_r && jr < p.queue_cap) push_ray(next, jr, child_r, wr, ni, slot, layer + 1, branch | (1u << (layer & 31u)), 0u);
 }
 
@@ -853,7 +883,7 @@ k_resolve(RenderParams p, const double* __restrict__ sample, float* accum)
     uint32_t k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= p.chunk_pixels) return;
     uint32_t x, y;
-    if (!pixel_of(p, p.chunk_t0 + k, x, y)) return;
+    pixel_of(p, p.chunk_t0 + k, x, y);
     uint32_t nn = p.n * p.n;
     d3 acum = mk(0, 0, 0);
     for (uint32_t sub = 0; sub < nn; ++sub) {
