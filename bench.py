@@ -63,12 +63,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path on a
+    # one-GPU box (the gather then goes through host memory); the default is RCCL.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-    device.init(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    device.init(dev_index)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
 
     W, H = args.width, args.height
     scene, _ = scenes.mesh_scene()
@@ -83,15 +91,31 @@ def main():
         return scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=1, max_depth=3, bias=1e-2,
                                   clear=(0.21, 0.78, 0.95), flags=flags | kflags)
 
-    fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    gathered = [torch.zeros_like(fb) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # two framebuffers: the gather of frame k (RCCL's own stream) overlaps the render of frame k+1
+    fbs = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+    fb = fbs[0]
+    gathered = [[torch.zeros((H, W, 3), dtype=torch.float32, device=comm_dev) for _ in range(world)]
+                if (world > 1 and rank == 0) else None for _ in range(2)]
+    pending = [None, None]
 
     def step_fn(step, flags):
-        fb.zero_()
-        st = ds.render_device(rd_for(step, flags), fb.data_ptr())
+        k = step & 1
+        if pending[k] is not None:
+            pending[k].wait()
+            pending[k] = None
+        buf = fbs[k]
+        buf.zero_()
+        st = ds.render_device(rd_for(step, flags), buf.data_ptr())
         if world > 1:
-            dist.gather(fb, gathered, dst=0)
+            src = buf if backend == "nccl" else buf.cpu()
+            pending[k] = dist.gather(src, gathered[k], dst=0, async_op=True)
         return st
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     # ---- algorithmic bytes of exactly the timed frames (untimed, counting kernels) ----
     alg_bytes = 0
@@ -105,6 +129,7 @@ def main():
 
     for s in range(args.warmup):
         step_fn(s, abi.FLAG_STAGE_TIMES)
+    drain()
 
     def sync():
         if world > 1:
@@ -120,10 +145,11 @@ def main():
         rays += st.rays
         launches += st.traverse_launches
         ms_trav += st.ms_traverse + st.ms_shadow
+    drain()
     sync()
     elapsed = time.perf_counter() - t0
 
-    tt = torch.tensor([elapsed, float(rays), ms_trav, float(launches), float(alg_bytes)], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed, float(rays), ms_trav, float(launches), float(alg_bytes)], dtype=torch.float64, device=comm_dev)
     if world > 1:
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -166,7 +192,8 @@ def main():
                 "mesh": "seeded bumpy UV sphere, 60024 triangles + 2 floor triangles",
                 "kd_tree": kd, "resolution": [W, H], "spp": 1, "light": "DirectionalLight(-1,-1,-1)",
                 "integrator": "whitted", "frames_per_step": world, "walk": args.walk,
-                "parallelism": f"frames x{world}, RCCL gather" if world > 1 else "single GPU",
+                "parallelism": (f"frames x{world}, {'RCCL' if backend == 'nccl' else backend} gather to rank 0"
+                                if world > 1 else "single GPU"),
             },
             "rays_per_frame": total_rays / frames,
             "ms_per_frame": round(elapsed / args.steps * 1e3, 4),
@@ -181,7 +208,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(desc, rd_for(args.warmup, 0))
+            out["cpu_baseline"] = cpu_baseline(desc, lambda f: rd_for(f, 0), args.warmup)
         print(json.dumps(out), flush=True)
     ds.close()
     if world > 1:
@@ -189,30 +216,26 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(desc, rd):
-    """The CPU oracle (a port of the reference's loop, OpenMP over pixels) on a bounded
-    sample of the same frame: a centred band of rows sized to about 10-20 s of CPU work."""
+def cpu_baseline(desc, rd_of_frame, first_frame, budget_s=12.0, max_frames=40):
+    """The CPU oracle (a port of the reference's loop, OpenMP over pixels in place of
+    concurrency::parallel_for) on a bounded sample of the same workload: whole frames of the
+    timed sequence, starting with the first timed one, until about `budget_s` seconds of CPU
+    work have been spent."""
     from oracle import binding as orc
-    from raytracer_amd import scenes as _s  # noqa: F401
-    import copy
-    probe = copy.copy(rd)
-    probe.tile_x0, probe.tile_w = 0, rd.width
-    probe.tile_y0, probe.tile_h = rd.height // 2 - 4, 8
+    rays = 0
+    frames = 0
+    threads = 1
     t0 = time.perf_counter()
-    _, _, st, threads = orc.render(desc, probe)
+    while frames < max_frames:
+        _, _, st, threads = orc.render(desc, rd_of_frame(first_frame + frames))
+        rays += st.rays
+        frames += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
     dt = time.perf_counter() - t0
-    rate = st.rays / dt
-    rows = int(max(8, min(rd.height, 12.0 * rate / max(st.rays / 8.0, 1.0))))
-    rows -= rows % 2
-    band = copy.copy(rd)
-    band.tile_x0, band.tile_w = 0, rd.width
-    band.tile_y0, band.tile_h = (rd.height - rows) // 2, rows
-    t0 = time.perf_counter()
-    _, _, st, threads = orc.render(desc, band)
-    dt = time.perf_counter() - t0
-    return {"value": round(st.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"rows {band.tile_y0}..{band.tile_y0 + rows - 1} of the first timed 1080p frame "
-                      f"({st.rays} rays, {dt:.1f} s, OpenMP schedule(dynamic,64), gcc -O2 -ffp-contract=off)"}
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{frames} whole 1080p frames of the timed sequence from frame {first_frame} on "
+                      f"({rays} rays, {dt:.1f} s; OpenMP schedule(dynamic,64), gcc -O2 -ffp-contract=off)"}
 
 
 if __name__ == "__main__":

@@ -268,14 +268,6 @@ struct StageTimer {
     }
 };
 
-int read_count(rtx_scene* sc, int which, uint32_t* out)
-{
-    HIP_TRY(hipMemcpyAsync(sc->ws.host_counts + which, sc->ws.counts + which, sizeof(uint32_t), hipMemcpyDeviceToHost, sc->stream));
-    HIP_TRY(hipStreamSynchronize(sc->stream));
-    *out = sc->ws.host_counts[which];
-    return RTX_OK;
-}
-
 }  // namespace
 
 extern "C" {

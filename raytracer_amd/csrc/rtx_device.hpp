@@ -105,10 +105,10 @@ struct PrimBox { double bmin[3]; double bmax[3]; };   // 48 bytes
 
 // Candidate-finding BVH over the shape boxes (built by the library, see rtx_bvh.hpp):
 // a node carries both children's boxes; child >= 0 is a node, < 0 is leaf ~child.
-struct BvhNode {                // 112 bytes, 16-byte aligned
+struct BvhNode {                // 128 bytes = one cache line
     PrimBox lbox, rbox;
     int32_t left, right;
-    int32_t pad[2];
+    int32_t pad[6];
 };
 constexpr int32_t kBvhEmpty = INT32_MIN;
 

@@ -10,7 +10,8 @@
 //
 // The reference recurses; here each recursion level is one pass over a queue of
 // rays that carry their accumulated weight, and every queue is compacted with
-// wave64 ballot / mbcnt prefix sums and one atomic per wave.
+// wave64 ballot / mbcnt prefix sums, combined per workgroup in LDS so that a
+// workgroup issues one atomic on the queue tail.
 #pragma once
 #include "rtx_device.hpp"
 
@@ -41,30 +42,14 @@ struct Counters { unsigned long long* c; };     // 8 global work counters, or nu
 
 struct RenderParams {
     rtx_render_desc d;
-    uint32_t chunk_t0;          // first padded pixel index of this chunk
-    uint32_t chunk_pixels;      // padded pixels in this chunk (multiple of 64)
-    uint32_t blocks_w;          // 8x8 pixel blocks per tile row
+    uint32_t chunk_t0;          // first pixel index (in the order of pixel_of) of this chunk
+    uint32_t chunk_pixels;      // pixels in this chunk
     uint32_t pass;
     uint32_t n;                 // pixel_multisample_n
     uint32_t shadow_per_hit;    // sum over lights of samples
     uint32_t queue_cap;         // entries a ray queue can hold; writes beyond are dropped and
     uint32_t shadow_cap;        //   the host turns the overshooting count into RTX_ERR_LIMIT
 };
-
-// ---- wave64 compaction --------------------------------------------------------------------
-// Must be called by every lane of the wave.  Returns this lane's output index
-// (valid when pred) after reserving room for the wave with one atomic.
-RTX_DEV uint32_t wave_reserve(bool pred, uint32_t* counter, uint32_t per_item = 1)
-{
-    unsigned long long mask = __ballot(pred);
-    uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    uint32_t total = (uint32_t)__popcll(mask);
-    uint32_t base = 0;
-    if (prefix == 0 && pred) base = atomicAdd(counter, total * per_item);     // first set lane
-    int leader = mask ? (int)__builtin_ctzll(mask) : 0;
-    base = __shfl(base, leader);
-    return base + prefix * per_item;
-}
 
 // ---- traversal core -------------------------------------------------------------------------
 template <bool COUNT>

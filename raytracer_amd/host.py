@@ -51,6 +51,7 @@ def lib():
     L.rth_frame.argtypes = [C.c_void_p, C.c_double]
     L.rth_kd_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.rth_scene_box.argtypes = [C.c_void_p, PD]
+    L.rth_frame_timings.argtypes = [C.c_void_p, PD]
     L.rth_make_camera.argtypes = [PD, PD, C.c_double, C.POINTER(abi.Camera)]
     _lib = L
     return L
@@ -170,6 +171,12 @@ class HostScene:
         out = (C.c_uint32 * 5)()
         self._L.rth_kd_stats(self._h, out)
         return dict(zip(["branches", "leaves", "leaf_refs", "depth", "max_leaf"], list(out)))
+
+    def frame_timings(self):
+        """Seconds the last frame() spent in redoAABBs, buildKDTree, flatten, freeing the old tree."""
+        out = (C.c_double * 4)()
+        self._L.rth_frame_timings(self._h, out)
+        return dict(zip(["redo_aabbs", "build_kd_tree", "flatten", "free_old_tree"], list(out)))
 
     def scene_box(self):
         out = (C.c_double * 6)()

@@ -2,6 +2,7 @@
 // assembled from Python (ctypes) exactly as the reference's main() assembles it
 // in C++ (Raytracer/Raytracer.cpp:448-557): create materials, push shapes and
 // lights, then per frame redoAABBs + buildKDTree + flatten.
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -21,6 +22,7 @@ struct rth_scene {
     FlatScene flat;
     AABB sceneBox;
     std::string error;
+    double timings[4] = {0, 0, 0, 0};      // seconds: redoAABBs, buildKDTree, flatten, freeing the old tree
 };
 
 static MovementFunction motionOf(int kind) {
@@ -161,11 +163,18 @@ const rtx_scene_desc* rth_frame(rth_scene* s, double current_time) {
         s->fi.lights.clear();
         for (auto& p : s->lights) s->fi.lights.push_back(p.get());
         s->fi.currentTime = current_time;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t0 = now();
         s->sceneBox = redoAABBs(s->fi);
+        double t1 = now();
         delete s->fi.kdTree;
         s->fi.kdTree = nullptr;
+        double t2 = now();
         s->fi.kdTree = buildKDTree(s->fi.shapes, s->sceneBox);
+        double t3 = now();
         s->flat.build(s->fi);
+        double t4 = now();
+        s->timings[0] = t1 - t0; s->timings[1] = t3 - t2; s->timings[2] = t4 - t3; s->timings[3] = t2 - t1;
         return &s->flat.desc();
     } catch (const std::exception& e) {
         s->error = e.what();
@@ -177,6 +186,11 @@ const rtx_scene_desc* rth_frame(rth_scene* s, double current_time) {
 void rth_kd_stats(const rth_scene* s, uint32_t out[5]) {
     out[0] = s->flat.stats.branches; out[1] = s->flat.stats.leaves; out[2] = s->flat.stats.leafRefs;
     out[3] = s->flat.stats.depth; out[4] = s->flat.stats.maxLeaf;
+}
+
+// seconds spent by the last rth_frame in redoAABBs, buildKDTree, flatten, freeing the previous tree
+void rth_frame_timings(const rth_scene* s, double out[4]) {
+    for (int i = 0; i < 4; ++i) out[i] = s->timings[i];
 }
 
 void rth_scene_box(const rth_scene* s, double out[6]) {

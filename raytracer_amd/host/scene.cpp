@@ -182,6 +182,8 @@ static void sortShapesMin(std::vector<Shape*>& shapes, Axis axis) {
     });
 }
 
+// (Building subtrees concurrently -- std::async or OpenMP tasks -- was tried and is slower
+// than this serial form: the work is dominated by allocating and copying shape lists.)
 KDNode* buildKDTree(std::vector<Shape*> shapes, AABB box, Axis axis, int recursionWithoutChange, int layer) {
     if (shapes.size() < 7 || recursionWithoutChange > 3 || layer > 20) return new KDLeaf(shapes);
     double value = shapes.at(shapes.size() / 2u)->boundingBox.mid[axis];
