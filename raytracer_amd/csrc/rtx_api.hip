@@ -227,6 +227,7 @@ int validate_scene(const rtx_scene_desc* s, uint32_t* kd_depth)
 }
 
 inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+inline dim3 trace_grid_for(size_t n) { return dim3((unsigned)((n + kTraceBlock - 1) / kTraceBlock)); }
 
 // Device time per stage: event pairs are recorded on the library stream without
 // waiting and read back once the stream has drained.
@@ -407,8 +408,53 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
             prim_leaf_first.swap(nf); prim_leaf_ids.swap(ni); prim_leaf_pos.swap(np);
         }
     }
+    // leaf cells and per-shape covering nodes for member_by_cell()
+    std::vector<PrimBox> leaf_cell(s->n_leaves);
+    {
+        PrimBox all;
+        for (int k = 0; k < 3; ++k) { all.bmin[k] = -big; all.bmax[k] = big; }
+        std::vector<std::pair<int32_t, PrimBox>> st;
+        st.push_back({s->kd_root, all});
+        while (!st.empty()) {
+            auto [node, cell] = st.back();
+            st.pop_back();
+            if (node < 0) { leaf_cell[(uint32_t)~node] = cell; continue; }
+            const Branch& b = branches[node];
+            for (int k = 0; k < 3; ++k) { cell.bmin[k] = std::max(cell.bmin[k], b.bmin[k]); cell.bmax[k] = std::min(cell.bmax[k], b.bmax[k]); }
+            PrimBox lo = cell, hi = cell;
+            lo.bmax[b.axis] = std::min(lo.bmax[b.axis], b.value);
+            hi.bmin[b.axis] = std::max(hi.bmin[b.axis], b.value);
+            st.push_back({b.lesser, lo});
+            st.push_back({b.greater, hi});
+        }
+    }
+    std::vector<int32_t> prim_lca(s->n_shapes, s->kd_root);
+    for (uint32_t p = 0; p < s->n_shapes; ++p) {
+        if (prim_leaf_first[p] == prim_leaf_first[p + 1]) continue;      // in no leaf: never looked up
+        const uint32_t lo = prim_leaf_ids[prim_leaf_first[p]], hi = prim_leaf_ids[prim_leaf_first[p + 1] - 1];
+        int32_t node = s->kd_root;
+        while (node >= 0) {
+            const Branch& b = branches[node];
+            if (hi < b.leaf_mid) node = b.lesser;
+            else if (lo >= b.leaf_mid) node = b.greater;
+            else break;
+        }
+        prim_lca[p] = node;
+    }
+    if (s->n_shapes > kBvhMaxShapes) {
+        delete sc;
+        return fail(RTX_ERR_LIMIT, "%u shapes: the candidate BVH addresses at most %u", s->n_shapes, kBvhMaxShapes);
+    }
     BvhBuild bvh;
     build_bvh(boxes, s->n_shapes, bvh);
+    std::vector<BvhPrim> bvh_prims(bvh.prims.size());
+    for (size_t i = 0; i < bvh.prims.size(); ++i) {
+        BvhPrim& q = bvh_prims[i];
+        std::memset(&q, 0, sizeof q);
+        q.shape = bvh.prims[i];
+        q.info = info[q.shape];
+        if ((q.info & 3u) == RTX_PRIM_TRIANGLE) std::memcpy(q.p, s->tri_position + 9 * (size_t)(q.info >> 2), sizeof q.p);
+    }
     d.bvh_root = bvh.root;
     sc->bvh_depth = (uint32_t)bvh.depth;
     double scale = 0.0;
@@ -423,11 +469,12 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     up(branch_cbox.data(), branch_cbox.size(), &d.branch_cbox);
     up(leaf_cbox.data(), leaf_cbox.size(), &d.leaf_cbox);
     up(bvh.nodes.data(), bvh.nodes.size(), &d.bvh_nodes);
-    up(bvh.leaves.data(), bvh.leaves.size(), &d.bvh_leaves);
-    up(bvh.prims.data(), bvh.prims.size(), &d.bvh_prims);
+    up(bvh_prims.data(), bvh_prims.size(), &d.bvh_prims);
     up(prim_leaf_first.data(), prim_leaf_first.size(), &d.prim_leaf_first);
     up(prim_leaf_ids.data(), prim_leaf_ids.size(), &d.prim_leaf_ids);
     up(prim_leaf_pos.data(), prim_leaf_pos.size(), &d.prim_leaf_pos);
+    up(leaf_cell.data(), leaf_cell.size(), &d.leaf_cell);
+    up(prim_lca.data(), prim_lca.size(), &d.prim_lca);
     up(leaves.data(), leaves.size(), &d.leaves);
     up(s->leaf_refs, (size_t)s->n_leaf_refs, &d.leaf_refs);
     up(boxes.data(), boxes.size(), &d.prim_box);
@@ -498,7 +545,7 @@ int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* directi
     if (counters) HIP_TRY(dalloc(n * 24, (void**)&d_ctr));
     const uint32_t linear = (flags & RTX_FLAG_LINEAR_SCAN) ? 1u : 0u;
 #define RTX_LAUNCH_API(MODE)                                                                                      \
-    hipLaunchKernelGGL(k_trace_api<MODE>, grid_for(n), dim3(kBlock), 0, sc->stream, sc->d, d_o, d_d, (uint32_t)n, \
+    hipLaunchKernelGGL(k_trace_api<MODE>, trace_grid_for(n), dim3(kTraceBlock), 0, sc->stream, sc->d, d_o, d_d, (uint32_t)n, \
                        linear, d_prim, d_depth, d_pos, d_nrm, d_uv, d_bary, d_lc, d_lh, d_seq, leaf_seq_cap, d_ctr)
     if (!(flags & RTX_FLAG_RENDER_WALK) || linear) RTX_LAUNCH_API(0);
     else if (flags & RTX_FLAG_KD_CULLED) RTX_LAUNCH_API(1);
@@ -531,7 +578,7 @@ static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const
     else mode = limit ? 4 : 3;
     Counters g;
     g.c = count ? sc->ws.work : nullptr;
-    dim3 grid = grid_for(n), block(kBlock);
+    dim3 grid = trace_grid_for(n), block(kTraceBlock);
 #define RTX_LAUNCH_TRACE(COUNT, MODE)                                                                                  \
     hipLaunchKernelGGL((k_trace_pool<COUNT, MODE>), grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
                        n_device, linear, hit_prim, hit_depth, g)

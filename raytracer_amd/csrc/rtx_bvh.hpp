@@ -21,13 +21,12 @@
 namespace rtx {
 
 constexpr int kBvhMaxDepth = 30;        // traversal stack is 32 entries
-constexpr uint32_t kBvhLeafSize = 4;
+constexpr uint32_t kBvhLeafSize = 4;       // at most 8: a leaf code keeps count - 1 in three bits
 
 struct BvhBuild {
     std::vector<BvhNode> nodes;
-    std::vector<uint2> leaves;          // (first, count) into prims
-    std::vector<uint32_t> prims;
-    int32_t root = 0;                   // >= 0 node, < 0 leaf ~root; kBvhEmpty when there are no shapes
+    std::vector<uint32_t> prims;        // shape ids in leaf order
+    int32_t root = 0;                   // >= 0 node, < 0 leaf code; kBvhEmpty when there are no shapes
     int depth = 0;
 };
 
@@ -68,10 +67,9 @@ struct Builder {
 
     int32_t make_leaf(uint32_t lo, uint32_t hi)
     {
-        uint32_t id = (uint32_t)out.leaves.size();
-        out.leaves.push_back(make_uint2((uint32_t)out.prims.size(), hi - lo));
+        uint32_t code = (uint32_t)out.prims.size() << 3 | (hi - lo - 1);
         for (uint32_t i = lo; i < hi; ++i) out.prims.push_back(order[i]);
-        return ~(int32_t)id;
+        return ~(int32_t)code;
     }
 
     // returns the split position in [lo+1, hi-1]
@@ -152,7 +150,7 @@ struct Builder {
 inline void build_bvh(const std::vector<PrimBox>& boxes, uint32_t n_shapes, BvhBuild& out)
 {
     out = BvhBuild();
-    if (n_shapes == 0) { out.root = kBvhEmpty; return; }
+    if (n_shapes == 0 || n_shapes > kBvhMaxShapes) { out.root = kBvhEmpty; return; }
     bvh_detail::Builder b(boxes, n_shapes, out);
     out.nodes.reserve(n_shapes / 2 + 1);
     out.root = b.build(0, n_shapes, 0);

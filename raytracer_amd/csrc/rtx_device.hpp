@@ -104,26 +104,40 @@ struct Branch {                 // 80 bytes, 16-byte aligned
 struct PrimBox { double bmin[3]; double bmax[3]; };   // 48 bytes
 
 // Candidate-finding BVH over the shape boxes (built by the library, see rtx_bvh.hpp):
-// a node carries both children's boxes; child >= 0 is a node, < 0 is leaf ~child.
+// a node carries both children's boxes; child >= 0 is a node, < 0 is a leaf whose code
+// ~child = first << 3 | (count - 1) names a run of bvh_prims.
 struct BvhNode {                // 128 bytes = one cache line
     PrimBox lbox, rbox;
     int32_t left, right;
     int32_t pad[6];
 };
 constexpr int32_t kBvhEmpty = INT32_MIN;
+constexpr uint32_t kBvhMaxShapes = 1u << 28;
+
+// The shapes of the BVH leaves, in leaf order, with what the traversal needs inline so a
+// leaf costs one dependent load instead of four (leaf -> shape id -> info -> positions).
+struct BvhPrim {                // 80 bytes
+    double p[9];                // triangle: its three positions; other shapes: unused
+    uint32_t shape;
+    uint32_t info;              // prim_info[shape]
+};
 
 struct DScene {
     int32_t root;
     int32_t bvh_root;
     const BvhNode* bvh_nodes;
-    const uint2* bvh_leaves;        // (first, count) into bvh_prims
-    const uint32_t* bvh_prims;
+    const BvhPrim* bvh_prims;
     // inverse leaf index: the KD leaves that reference shape p are
     // prim_leaf_ids[prim_leaf_first[p] .. prim_leaf_first[p+1]) in increasing order, and
     // prim_leaf_pos holds the shape's position in leaf_refs for each of them
     const uint32_t* prim_leaf_first;
     const uint32_t* prim_leaf_ids;
     const uint32_t* prim_leaf_pos;
+    // shortcut for the common case of the verification: per leaf the intersection of all its
+    // ancestors' boxes and split half-spaces, per shape the deepest KD node (or leaf, < 0)
+    // whose subtree holds every leaf that references the shape
+    const PrimBox* leaf_cell;
+    const int32_t* prim_lca;
     uint32_t n_branches, n_leaves, n_leaf_refs, n_shapes, n_prims, n_lights, n_materials, n_textures;
     double scene_scale;             // largest |coordinate| of the scene box
     const Branch* branches;

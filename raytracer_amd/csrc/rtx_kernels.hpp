@@ -18,6 +18,7 @@
 namespace rtx {
 
 constexpr int kBlock = 256;             // threads per workgroup (4 waves)
+constexpr int kTraceBlock = 64;         // workgroup of the traversal kernels
 constexpr int kStack = 32;              // per-lane stack entries: KD depth is capped at 21 (KDTree.cpp:69), BVH depth at 30
 
 // ---- ray queue (SoA, resident in HBM) ---------------------------------------------------
@@ -101,7 +102,7 @@ RTX_DEV void scan_refs(const DScene& s, const uint32_t* __restrict__ refs, uint3
 }
 
 // traverseKDTree (KDTree.cpp:158-204) as an iterative walk: lesser subtree first,
-// the greater child is deferred on a per-lane stack kept in LDS (stack[level*kBlock]).
+// the greater child is deferred on a per-lane stack kept in LDS (stack[level*kTraceBlock]).
 template <bool COUNT>
 RTX_DEV void trace_lane(const DScene& s, d3 o, d3 d, bool linear, int32_t* stack, int32_t& best_prim,
                         double& best_depth, Work<COUNT>& w, uint32_t* seq, uint32_t seq_cap)
@@ -130,7 +131,7 @@ RTX_DEV void trace_lane(const DScene& s, d3 o, d3 d, bool linear, int32_t* stack
                 else { only_greater = exit_ > value; only_lesser = false; }
                 if (only_greater) { node = greater; }
                 else {
-                    if (!only_lesser) { stack[sp * kBlock] = greater; ++sp; }
+                    if (!only_lesser) { stack[sp * kTraceBlock] = greater; ++sp; }
                     node = lesser;
                 }
                 continue;
@@ -148,7 +149,7 @@ RTX_DEV void trace_lane(const DScene& s, d3 o, d3 d, bool linear, int32_t* stack
         }
         if (sp == 0) break;
         --sp;
-        node = stack[sp * kBlock];
+        node = stack[sp * kTraceBlock];
     }
 }
 
@@ -231,7 +232,7 @@ RTX_DEV void trace_lane_culled(const DScene& s, d3 o, d3 d, double limit, int32_
                     else if (only_lesser) node = lesser;
                     else {
                         bool lesser_first = da >= 0.0;
-                        stack[sp * kBlock] = lesser_first ? greater : lesser;
+                        stack[sp * kTraceBlock] = lesser_first ? greater : lesser;
                         ++sp;
                         node = lesser_first ? lesser : greater;
                     }
@@ -280,7 +281,7 @@ RTX_DEV void trace_lane_culled(const DScene& s, d3 o, d3 d, double limit, int32_
         }
         if (sp == 0) break;
         --sp;
-        node = stack[sp * kBlock];
+        node = stack[sp * kTraceBlock];
     }
     if constexpr (ANYHIT) { best_depth = kInf; best_prim = -1; }     // nothing at or before the light
 }
@@ -379,6 +380,34 @@ RTX_DEV bool member_through_point(const DScene& s, uint32_t shape, d3 p, d3 o, d
     return at < end && s.prim_leaf_ids[at] == leaf;
 }
 
+// Cheapest existence proof, for a point p = o + d*t (t >= 0) of the ray.  When p lies inside
+// the cell of a KD leaf -- inside every ancestor's box and on the leaf's side of every
+// ancestor's split plane -- by a margin far above the rounding error of the slab arithmetic
+// (margin ~1e-9 of the scene size, errors ~1e-15), traverseKDTree provably reaches that
+// leaf: at each ancestor the box is hit over a parameter interval of positive length around
+// t, and since the coordinate along the split axis is monotone in the parameter, either the
+// entry point or the exit point is on p's side of the plane by more than the error, which is
+// exactly what KDTree.cpp:171-194 tests.  The leaf is located from the deepest node that
+// covers all leaves of the shape, so only a few levels are walked and only with (axis, value).
+// A `false` only means "not shown this way".
+RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 p, double margin)
+{
+    int32_t node = s.prim_lca[shape];
+    while (node >= 0) {
+        const Branch* b = s.branches + node;
+        node = pick(p, b->axis) <= b->value ? b->lesser : b->greater;
+    }
+    uint32_t leaf = (uint32_t)~node;
+    const PrimBox* c = s.leaf_cell + leaf;
+    bool inside = p.x - margin >= c->bmin[0] && p.x + margin <= c->bmax[0] &&
+                  p.y - margin >= c->bmin[1] && p.y + margin <= c->bmax[1] &&
+                  p.z - margin >= c->bmin[2] && p.z + margin <= c->bmax[2];
+    if (!inside) return false;
+    const uint32_t first = s.prim_leaf_first[shape], end = s.prim_leaf_first[shape + 1];
+    uint32_t at = lower_bound_u32(s.prim_leaf_ids, first, end, leaf);
+    return at < end && s.prim_leaf_ids[at] == leaf;
+}
+
 // Optimistic form: the BVH walk treats every geometric candidate as genuine, so its loop
 // holds no long divergent section; the winner is verified once, after the loop, when the
 // lanes of the wave have reconverged.  Returns false when the optimistic answer cannot be
@@ -413,7 +442,7 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
             int32_t left = n->left, right = n->right;
             if (hl && hr) {
                 bool left_first = lmin <= rmin;
-                stack[sp * kBlock] = left_first ? right : left;
+                stack[sp * kTraceBlock] = left_first ? right : left;
                 ++sp;
                 node = left_first ? left : right;
                 continue;
@@ -421,21 +450,20 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
             if (hl) { node = left; continue; }
             if (hr) { node = right; continue; }
         } else {
-            uint2 fc = s.bvh_leaves[(uint32_t)~node];
-            for (uint32_t k = 0; k < fc.y; ++k) {
-                uint32_t shape = s.bvh_prims[fc.x + k];
-                double tmin, tmax;
-                slab_finite(s.prim_box + shape, o, inv, tmin, tmax);
-                if constexpr (COUNT) w.aabb++;
-                if (!(tmin <= tmax && tmax >= 0.0)) continue;
-                uint32_t info = s.prim_info[shape];
+            const uint32_t code = (uint32_t)~node;
+            const BvhPrim* q = s.bvh_prims + (code >> 3);
+            const uint32_t count = (code & 7u) + 1u;
+            for (uint32_t k = 0; k < count; ++k, ++q) {
+                // Shape::rayAABB && rayHit (KDTree.cpp:208-211) commute: rayHit first, and the
+                // shape's box is only fetched for a hit that could change the result
+                uint32_t shape = q->shape, info = q->info;
                 uint32_t type = info & 3u, idx = info >> 2;
                 double depth = kInf;
                 uint32_t rp = shape;
                 bool ok;
                 if (type == RTX_PRIM_TRIANGLE) {
                     if constexpr (COUNT) w.tri++;
-                    ok = triangle_depth(s.tri_pos + 9 * (size_t)idx, o, d, depth);
+                    ok = triangle_depth(q->p, o, d, depth);
                 } else if (type == RTX_PRIM_SPHERE) {
                     if constexpr (COUNT) w.sph++;
                     ok = sphere_t(ld3(s.sph_center + 3 * (size_t)idx), s.sph_r2[idx], o, d, depth);
@@ -444,25 +472,32 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                     ok = biconvex_depth(s, idx, o, d, depth, rp);
                 }
                 if (!ok) continue;
+                if (ANYHIT ? !(depth <= limit) : !(depth <= best_depth)) continue;
+                double tmin, tmax;
+                slab_finite(s.prim_box + shape, o, inv, tmin, tmax);
+                if constexpr (COUNT) w.aabb++;
+                if (!(tmin <= tmax && tmax >= 0.0)) continue;
                 if constexpr (ANYHIT) {
-                    if (depth <= limit) { best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; done = true; break; }
+                    best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; done = true; break;
                 } else if (depth < best_depth) {
                     if constexpr (COUNT) w.accepted++;
                     best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; tie = false;
                     double bd = best_depth * (1.0 + 1e-7) + abs_margin;
                     bound2 = bd * bd;
-                } else if (depth == best_depth && (int32_t)rp != best_prim) {
+                } else if ((int32_t)rp != best_prim) {
                     tie = true;
                 }
             }
         }
         if (done || sp == 0) break;
         --sp;
-        node = stack[sp * kBlock];
+        node = stack[sp * kTraceBlock];
     }
     if (best_prim < 0) return true;                 // no geometric candidate at all: the reference finds none either
     if (tie) return false;
-    return member_through_point<COUNT>(s, best_shape, o + (d * best_depth), o, d, inv, w) ||
+    d3 at = o + (d * best_depth);
+    if (member_by_cell(s, best_shape, at, abs_margin)) return true;
+    return member_through_point<COUNT>(s, best_shape, at, o, d, inv, w) ||
            first_visited_position<COUNT>(s, best_shape, o, d, inv, w) != kNoPosition;
 }
 
@@ -487,14 +522,14 @@ RTX_DEV void add_counters(Counters, const Work<false>&) {}
 // order and reports leaf sequences; MODE 1 (culled KD walk) and 3 (BVH) are the render
 // path's walks, for which the leaf outputs describe nothing the reference does.
 template <int MODE>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kTraceBlock)
 k_trace_api(DScene s, const double* __restrict__ origin, const double* __restrict__ direction, uint32_t n,
             uint32_t linear, int32_t* prim, double* depth, double* position, double* normal, double* uv, double* bary,
             uint32_t* leaf_count, unsigned long long* leaf_hash, uint32_t* leaf_seq, uint32_t leaf_seq_cap,
             uint32_t* counters)
 {
-    __shared__ int32_t stack[kStack * kBlock];
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ int32_t stack[kStack * kTraceBlock];
+    uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
     if (i >= n) return;
     Ray r = make_ray(ld3(origin + 3 * (size_t)i), ld3(direction + 3 * (size_t)i));
     Work<true> w;
@@ -528,14 +563,14 @@ k_trace_api(DScene s, const double* __restrict__ origin, const double* __restric
 // MODE 0: the reference's walk order; 1 / 2: culled KD walk, closest hit / any hit with
 // depth <= limit[i] (depth = +inf when there is none); 3 / 4: the same through the BVH.
 template <bool COUNT, int MODE>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kTraceBlock)
 k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
              const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
              const double* __restrict__ limit, uint32_t n, const uint32_t* __restrict__ n_device, uint32_t linear,
              int32_t* hit_prim, double* hit_depth, Counters g)
 {
-    __shared__ int32_t stack[kStack * kBlock];
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ int32_t stack[kStack * kTraceBlock];
+    uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
     // the grid is sized for n; when the real queue length is only known on the device
     // (n_device), the surplus workgroups leave here
     if (n_device) n = min(n, *n_device);
