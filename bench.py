@@ -123,7 +123,7 @@ def main():
                            "content_tests")}
     for s in range(args.steps):
         st = ds.render_device(rd_for(args.warmup + s, abi.FLAG_COUNTERS), fb.data_ptr())
-        alg_bytes += abi.algorithmic_bytes(st)
+        alg_bytes += abi.algorithmic_bytes(st, args.walk)
         for k in work:
             work[k] += getattr(st, k)
 

@@ -134,17 +134,26 @@ class Stats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
-def algorithmic_bytes(stats):
-    """Bytes the reference's data layout moves for the counted work.
+def algorithmic_bytes(stats, walk="reference"):
+    """Bytes the counted work has to read and write, record by record.
 
-    Per ray: 72 B per KD branch visit (box, split value, axis, two children),
-    8 B per leaf visit (first, count), 52 B per shape-box test (box + 4 B leaf
-    reference), 72 B per triangle test (three positions), 32 B per sphere test
-    (centre + r^2), 124 B per accepted hit (normals, uvs, material id) and 88 B
-    of ray in / hit out.
+    Reference layout (walk "reference" / "kd-culled"): 72 B per KD branch visit
+    (box, split value, axis, two children), 8 B per leaf visit (first, count),
+    52 B per shape-box test (box + 4 B leaf reference), 72 B per triangle test
+    (three positions), 32 B per sphere test (centre + r^2), 124 B per accepted
+    hit (normals, uvs, material id) and 88 B of ray in / hit out; the culled KD
+    walk additionally reads one 48 B content box per node it considers.
+
+    Walk "bvh": a 64 B node per two child-box tests (32 B per test), 80 B per
+    triangle test (positions + shape id + type, inline in the leaf), 48 B per
+    shape-box test (only made for hits that could change the result); the KD
+    branch visits counted are those of the membership verification (72 B).
     """
     rays = stats.rays_primary + stats.rays_secondary + stats.rays_shadow
-    # the culled walk additionally reads one 48 B content box per node it considers
+    if walk == "bvh":
+        return (32 * stats.content_tests + 72 * stats.branch_visits + 8 * stats.leaf_visits + 48 * stats.aabb_tests
+                + 80 * stats.triangle_tests + 32 * stats.sphere_tests + 124 * stats.hits_accepted
+                + 88 * rays)
     return (48 * stats.content_tests + 72 * stats.branch_visits + 8 * stats.leaf_visits + 52 * stats.aabb_tests
             + 72 * stats.triangle_tests + 32 * stats.sphere_tests + 124 * stats.hits_accepted
             + 88 * rays)

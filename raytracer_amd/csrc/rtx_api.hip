@@ -185,6 +185,7 @@ int validate_scene(const rtx_scene_desc* s, uint32_t* kd_depth)
     if (s->abi_version != RTX_ABI_VERSION) return fail(RTX_ERR_INVALID, "abi_version %u, library speaks %u", s->abi_version, RTX_ABI_VERSION);
     if (s->n_shapes > s->n_prims) return fail(RTX_ERR_INVALID, "n_shapes > n_prims");
     if (s->n_prims >= (1u << 30)) return fail(RTX_ERR_LIMIT, "too many primitives");
+    if (s->n_branches >= kKdMaxNodes || s->n_leaves >= kKdMaxNodes) return fail(RTX_ERR_LIMIT, "too many KD nodes");
     for (uint32_t i = 0; i < s->n_prims; ++i) {
         uint32_t idx = s->prim_index[i];
         switch (s->prim_type[i]) {
@@ -428,6 +429,12 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
             st.push_back({b.greater, hi});
         }
     }
+    std::vector<KdSplit> kd_split(s->n_branches);
+    for (uint32_t i = 0; i < s->n_branches; ++i) {
+        kd_split[i].value = branches[i].value;
+        kd_split[i].lesser_axis = branches[i].lesser * 4 + branches[i].axis;
+        kd_split[i].greater = branches[i].greater;
+    }
     std::vector<int32_t> prim_lca(s->n_shapes, s->kd_root);
     for (uint32_t p = 0; p < s->n_shapes; ++p) {
         if (prim_leaf_first[p] == prim_leaf_first[p + 1]) continue;      // in no leaf: never looked up
@@ -475,6 +482,7 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     up(prim_leaf_pos.data(), prim_leaf_pos.size(), &d.prim_leaf_pos);
     up(leaf_cell.data(), leaf_cell.size(), &d.leaf_cell);
     up(prim_lca.data(), prim_lca.size(), &d.prim_lca);
+    up(kd_split.data(), kd_split.size(), &d.kd_split);
     up(leaves.data(), leaves.size(), &d.leaves);
     up(s->leaf_refs, (size_t)s->n_leaf_refs, &d.leaf_refs);
     up(boxes.data(), boxes.size(), &d.prim_box);

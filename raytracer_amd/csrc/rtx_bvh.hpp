@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 #include <numeric>
 #include <vector>
@@ -44,6 +45,10 @@ struct Box {
         return 2.0 * (d0 * d1 + d1 * d2 + d2 * d0);
     }
 };
+
+// nearest floats that do not lie inside (x, x): rounding outwards
+inline float float_below(double x) { float f = (float)x; return (double)f > x ? std::nextafterf(f, -std::numeric_limits<float>::infinity()) : f; }
+inline float float_above(double x) { float f = (float)x; return (double)f < x ? std::nextafterf(f, std::numeric_limits<float>::infinity()) : f; }
 
 struct Builder {
     const std::vector<PrimBox>& boxes;
@@ -139,7 +144,11 @@ struct Builder {
         int32_t left = build(lo, mid, depth + 1);
         int32_t right = build(mid, hi, depth + 1);
         BvhNode& n = out.nodes[id];
-        for (int k = 0; k < 3; ++k) { n.lbox.bmin[k] = l.mn[k]; n.lbox.bmax[k] = l.mx[k]; n.rbox.bmin[k] = r.mn[k]; n.rbox.bmax[k] = r.mx[k]; }
+        std::memset(&n, 0, sizeof n);
+        for (int k = 0; k < 3; ++k) {
+            n.lmin[k] = float_below(l.mn[k]); n.lmax[k] = float_above(l.mx[k]);
+            n.rmin[k] = float_below(r.mn[k]); n.rmax[k] = float_above(r.mx[k]);
+        }
         n.left = left; n.right = right;
         return (int32_t)id;
     }

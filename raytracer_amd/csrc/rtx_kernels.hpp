@@ -186,6 +186,24 @@ RTX_DEV void slab_finite(const PrimBox* __restrict__ b, d3 o, d3 inv, double& tm
     tmax = __builtin_fmin(__builtin_fmax(t0x, t1x), __builtin_fmin(__builtin_fmax(t0y, t1y), __builtin_fmax(t0z, t1z)));
 }
 
+// the same two tests on a box held in registers
+RTX_DEV void slab_finite(d3 bmin, d3 bmax, d3 o, d3 inv, double& tmin, double& tmax)
+{
+    double t0x = (bmin.x - o.x) * inv.x, t1x = (bmax.x - o.x) * inv.x;
+    double t0y = (bmin.y - o.y) * inv.y, t1y = (bmax.y - o.y) * inv.y;
+    double t0z = (bmin.z - o.z) * inv.z, t1z = (bmax.z - o.z) * inv.z;
+    tmin = __builtin_fmax(__builtin_fmin(t0x, t1x), __builtin_fmax(__builtin_fmin(t0y, t1y), __builtin_fmin(t0z, t1z)));
+    tmax = __builtin_fmin(__builtin_fmax(t0x, t1x), __builtin_fmin(__builtin_fmax(t0y, t1y), __builtin_fmax(t0z, t1z)));
+}
+
+RTX_DEV double box_distance2(d3 bmin, d3 bmax, d3 o)
+{
+    double ex = __builtin_fmax(__builtin_fmax(bmin.x - o.x, o.x - bmax.x), 0.0);
+    double ey = __builtin_fmax(__builtin_fmax(bmin.y - o.y, o.y - bmax.y), 0.0);
+    double ez = __builtin_fmax(__builtin_fmax(bmin.z - o.z, o.z - bmax.z), 0.0);
+    return (ex * ex + ey * ey) + ez * ez;
+}
+
 RTX_DEV double box_distance2(const PrimBox* __restrict__ b, d3 o)
 {
     double ex = __builtin_fmax(__builtin_fmax(b->bmin[0] - o.x, o.x - b->bmax[0]), 0.0);
@@ -394,8 +412,8 @@ RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 p, double margin
 {
     int32_t node = s.prim_lca[shape];
     while (node >= 0) {
-        const Branch* b = s.branches + node;
-        node = pick(p, b->axis) <= b->value ? b->lesser : b->greater;
+        const KdSplit k = s.kd_split[node];
+        node = pick(p, k.lesser_axis & 3) <= k.value ? (k.lesser_axis >> 2) : k.greater;
     }
     uint32_t leaf = (uint32_t)~node;
     const PrimBox* c = s.leaf_cell + leaf;
@@ -432,14 +450,18 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     bool done = false;
     while (!done) {
         if (node >= 0) {
-            const BvhNode* n = s.bvh_nodes + node;
+            // one node = four 16-byte loads
+            const float4* n = reinterpret_cast<const float4*>(s.bvh_nodes + node);
+            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            const d3 lb0 = mk(n0.x, n0.y, n0.z), lb1 = mk(n0.w, n1.x, n1.y);
+            const d3 rb0 = mk(n1.z, n1.w, n2.x), rb1 = mk(n2.y, n2.z, n2.w);
             double lmin, lmax, rmin, rmax;
-            slab_finite(&n->lbox, o, inv, lmin, lmax);
-            slab_finite(&n->rbox, o, inv, rmin, rmax);
+            slab_finite(lb0, lb1, o, inv, lmin, lmax);
+            slab_finite(rb0, rb1, o, inv, rmin, rmax);
             if constexpr (COUNT) w.content += 2;
-            bool hl = lmin <= lmax && lmax >= 0.0 && !(box_distance2(&n->lbox, o) > bound2);
-            bool hr = rmin <= rmax && rmax >= 0.0 && !(box_distance2(&n->rbox, o) > bound2);
-            int32_t left = n->left, right = n->right;
+            bool hl = lmin <= lmax && lmax >= 0.0 && !(box_distance2(lb0, lb1, o) > bound2);
+            bool hr = rmin <= rmax && rmax >= 0.0 && !(box_distance2(rb0, rb1, o) > bound2);
+            int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
             if (hl && hr) {
                 bool left_first = lmin <= rmin;
                 stack[sp * kTraceBlock] = left_first ? right : left;
