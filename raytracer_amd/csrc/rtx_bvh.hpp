@@ -21,7 +21,7 @@
 
 namespace rtx {
 
-constexpr int kBvhMaxDepth = 30;        // traversal stack is 32 entries
+constexpr int kBvhMaxDepth = 22;        // traversal stack is 24 entries
 constexpr uint32_t kBvhLeafSize = 4;       // at most 8: a leaf code keeps count - 1 in three bits
 
 struct BvhBuild {

@@ -120,7 +120,7 @@ struct BvhNode {                // 64 bytes
     int32_t pad[2];
 };
 constexpr int32_t kBvhEmpty = INT32_MIN;
-constexpr uint32_t kBvhMaxShapes = 1u << 28;
+constexpr uint32_t kBvhMaxShapes = 1u << 24;     // 4 per leaf under the BVH depth cap of 22
 
 // The shapes of the BVH leaves, in leaf order, with what the traversal needs inline so a
 // leaf costs one dependent load instead of four (leaf -> shape id -> info -> positions).

@@ -19,7 +19,7 @@ namespace rtx {
 
 constexpr int kBlock = 256;             // threads per workgroup (4 waves)
 constexpr int kTraceBlock = 64;         // workgroup of the traversal kernels
-constexpr int kStack = 32;              // per-lane stack entries: KD depth is capped at 21 (KDTree.cpp:69), BVH depth at 30
+constexpr int kStack = 24;              // per-lane stack entries: KD depth is capped at 21 (KDTree.cpp:69), BVH depth at 22
 
 // ---- ray queue (SoA, resident in HBM) ---------------------------------------------------
 struct RayQueue {
