@@ -148,3 +148,65 @@ def test_render_walks_find_the_reference_hit(gpu, name, make, t, box, walk):
         same = (g == w) | ((g != g) & (w != w)) if g.dtype.kind == "f" else g == w
         assert same.all(), f"{key}: {np.count_nonzero(~same)} of {same.size} differ"
     assert (want["prim"] >= 0).mean() > 0.05
+
+
+def _tie_scene():
+    """Random triangles each present twice (two shapes, identical vertices: every hit is an
+    exact depth tie that only the reference's visit order resolves), in both windings (so rays
+    from either side hit, and triangles behind a ray origin are hits too, Triangle.cpp has no
+    t >= 0 test), plus two coplanar overlapping quads."""
+    from raytracer_amd import host
+    rng = np.random.default_rng(11)
+    scene = host.HostScene()
+    m = scene.material("PlainWhiteTees")
+    n = 400
+    c = rng.uniform(-5, 5, size=(n, 1, 3))
+    tri = c + rng.normal(scale=0.8, size=(n, 3, 3))
+    flipped = tri[:, ::-1, :]
+    order = rng.permutation(4 * n)
+    pos = np.concatenate([tri, tri, flipped, flipped])[order]
+    nrm = np.tile([0.0, 1.0, 0.0], (4 * n, 3, 1))
+    uv = np.tile([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]], (4 * n, 1, 1))
+    scene.triangles(pos, nrm, uv, m)
+    quad = np.array([[[-6, -6, 0.25], [6, -6, 0.25], [6, 6, 0.25]], [[-6, -6, 0.25], [6, 6, 0.25], [-6, 6, 0.25]],
+                     [[-3, -6, 0.25], [9, -6, 0.25], [9, 6, 0.25]], [[-3, -6, 0.25], [9, 6, 0.25], [-3, 6, 0.25]]], dtype=np.float64)
+    scene.triangles(quad, nrm[:4], uv[:4], m)
+    return scene
+
+
+@pytest.mark.parametrize("walk", ["bvh", "kd_culled"])
+def test_exact_depth_ties_follow_the_reference_visit_order(gpu, walk):
+    scene = _tie_scene()
+    desc = scene.frame(0.0)
+    rng = np.random.default_rng(12)
+    o, d = _random_rays(rng, 40000, box=7.0)
+    flags = abi.FLAG_RENDER_WALK | (abi.FLAG_KD_CULLED if walk == "kd_culled" else 0)
+    with gpu.DeviceScene(desc) as ds:
+        got = ds.trace_closest(o, d, flags=flags)
+        ref = ds.trace_closest(o, d)
+    want = orc.trace_closest(desc, o, d)
+    assert np.array_equal(ref["prim"], want["prim"])
+    assert np.array_equal(got["prim"], want["prim"]), f"{np.count_nonzero(got['prim'] != want['prim'])} ids differ"
+    assert np.array_equal(got["depth"], want["depth"])
+    assert (want["prim"] >= 0).mean() > 0.3
+
+
+def test_bvh_walk_falls_back_on_ties_only(gpu):
+    """Work counters of a render: on the tie scene the BVH walk must send rays through the
+    reference-order walk (fallback_rays > 0) and still produce the reference image; on an
+    ordinary mesh no ray needs it."""
+    from raytracer_amd import host
+    for make, expect in ((_tie_scene, True), (lambda: scenes.mesh_scene(slices=60, stacks=30)[0], False)):
+        scene = make()
+        if expect:
+            scene.directional_light((-1.0, -1.0, -1.0))
+        desc = scene.frame(0.0)
+        cam = host.make_camera((0.0, 0.5, 12.0), (0.0, 0.0, 0.0))
+        imgs = {}
+        with gpu.DeviceScene(desc) as ds:
+            for name, fl in (("bvh", 0), ("ref", abi.FLAG_REFERENCE_ORDER)):
+                rd = scenes.render_desc(160, 120, camera=cam, max_depth=2, bias=1e-3, flags=fl | abi.FLAG_COUNTERS)
+                imgs[name], st = ds.render(rd)
+                if name == "bvh":
+                    assert (st.fallback_rays > 0) == expect, st.fallback_rays
+        assert np.array_equal(imgs["bvh"], imgs["ref"])

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Single-GPU timings of the five benchmark configurations (bench.py times configs[1] only).
+
+    python tools/bench_configs.py [c1 c2 c3 c4w c4p c5 ...] [--frames K]
+
+Prints one JSON line per configuration: rays by kind, Mrays/s, ms/frame, per-stage GPU times,
+host scene-build times.  Framebuffers stay in HBM; scene build / flatten / upload are timed
+separately and are not part of ms_per_frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def configs():
+    from raytracer_amd import abi, scenes
+
+    def c1():
+        s, cam = scenes.whitted_scene()
+        return s, lambda f: scenes.render_desc(640, 480, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=1, max_depth=1,
+                                               bias=1e-3, flags=abi.FLAG_WHITTED_REFLECT), 0.0
+
+    def c2():
+        s, _ = scenes.mesh_scene()
+        return s, lambda f: scenes.render_desc(1920, 1080, integrator=abi.INTEGRATOR_WHITTED, camera=scenes.orbit_camera(f / 30.0),
+                                               n=1, max_depth=3, bias=1e-2, clear=(0.21, 0.78, 0.95)), 0.0
+
+    def c3():
+        s, cam = scenes.lens_scene()
+        return s, lambda f: scenes.render_desc(1920, 1080, integrator=abi.INTEGRATOR_PATH, camera=cam, n=1, max_depth=8,
+                                               bias=1e-4, frame=f), 0.0
+
+    def c4w():
+        s, _ = scenes.mesh_scene(ggx=True, square_light=True)
+        return s, lambda f: scenes.render_desc(1920, 1080, integrator=abi.INTEGRATOR_WHITTED, camera=scenes.orbit_camera(f / 30.0),
+                                               n=4, light_n=2, max_depth=3, bias=1e-2, frame=f), 0.0
+
+    def c4p():
+        s, _ = scenes.mesh_scene(ggx=True, square_light=True)
+        # path-tracing semantics need an emitter: the square light's place is taken by an emissive sphere
+        s.sphere((0.0, 10.0, 0.0), 2.0, s.material("PlainWhiteTees", emission=(8.0, 8.0, 8.0)))
+        return s, lambda f: scenes.render_desc(1920, 1080, integrator=abi.INTEGRATOR_PATH, camera=scenes.orbit_camera(f / 30.0),
+                                               n=4, max_depth=8, bias=1e-3, frame=f), 0.0
+
+    def c5():
+        s = scenes.animated_scene(copies=16)
+        return s, lambda f: scenes.render_desc(3840, 2160, integrator=abi.INTEGRATOR_PATH,
+                                               camera=scenes.orbit_camera(f / 30.0, radius=30.0, height=6.0),
+                                               n=8, max_depth=8, bias=1e-3, frame=f), None
+
+    return {"c1": c1, "c2": c2, "c3": c3, "c4w": c4w, "c4p": c4p, "c5": c5}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("names", nargs="*", default=["c1", "c2", "c3", "c4w", "c4p"])
+    ap.add_argument("--frames", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    from raytracer_amd import abi, device
+    device.init(0)
+    table = configs()
+    stream = torch.cuda.current_stream().cuda_stream
+    for name in args.names:
+        scene, rd_of, fixed_t = table[name]()
+        animated = fixed_t is None
+        frames = 2 if name == "c5" else args.frames
+        t0 = time.perf_counter()
+        desc = scene.frame(0.0)
+        t_host = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ds = device.DeviceScene(desc, stream=stream)
+        t_up = time.perf_counter() - t0
+        rd0 = rd_of(0)
+        fb = torch.zeros((rd0.height, rd0.width, 3), dtype=torch.float32, device="cuda")
+        ds.render_device(rd_of(0), fb.data_ptr())           # warm-up
+        torch.cuda.synchronize()
+        acc = {}
+        rays = {"rays_primary": 0, "rays_secondary": 0, "rays_shadow": 0}
+        host_s = 0.0
+        t0 = time.perf_counter()
+        for f in range(frames):
+            if animated:
+                th = time.perf_counter()
+                ds.close()
+                desc = scene.frame((1 + f) / 30.0)
+                ds = device.DeviceScene(desc, stream=stream)
+                host_s += time.perf_counter() - th
+            fb.zero_()
+            rd = rd_of(1 + f)
+            rd.flags |= abi.FLAG_STAGE_TIMES
+            st = ds.render_device(rd, fb.data_ptr())
+            for k in rays:
+                rays[k] += getattr(st, k)
+            for k in ("ms_generate", "ms_traverse", "ms_shade", "ms_shadow", "ms_resolve"):
+                acc[k] = acc.get(k, 0.0) + getattr(st, k) / frames
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0 - host_s
+        total = sum(rays.values())
+        out = {"config": name, "resolution": [rd0.width, rd0.height], "spp": rd0.pixel_multisample_n ** 2,
+               "shapes": desc.n_shapes, "kd": scene.kd_stats(), "frames": frames,
+               **{k: v // frames for k, v in rays.items()},
+               "Mrays_per_s": round(total / dt / 1e6, 1), "ms_per_frame": round(dt / frames * 1e3, 3),
+               "stage_ms": {k: round(v, 3) for k, v in acc.items()},
+               "host_first_frame_s": round(t_host, 3), "upload_s": round(t_up, 3),
+               "host_rebuild_s_per_frame": round(host_s / frames, 3) if animated else None,
+               "finite": bool(torch.isfinite(fb).all().item())}
+        print(json.dumps(out), flush=True)
+        ds.close()
+        scene.close()
+
+
+if __name__ == "__main__":
+    main()
