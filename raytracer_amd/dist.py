@@ -39,12 +39,14 @@ def _gather_to_rank0(local, world, rank, group=None):
     return out
 
 
-def render_frame_bands(render_rect, width, height, device, band_rows=64, group=None):
+def render_frame_bands(render_rect, width, height, device, band_rows=64, group=None, comm_device=None):
     """Render one frame cooperatively.
 
     render_rect(x0, y0, w, h, out) must accumulate the rectangle's float32 RGB into `out`
     (a [h, w, 3] tensor on `device`, zero-initialised here).  Returns the assembled
-    [height, width, 3] frame on rank 0 and None on the other ranks.
+    [height, width, 3] frame on rank 0 and None on the other ranks.  `comm_device` is where
+    the gather runs when the process group cannot move `device` tensors (gloo with GPU
+    framebuffers); the frame is then returned there.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -55,10 +57,12 @@ def render_frame_bands(render_rect, width, height, device, band_rows=64, group=N
     mine = band_rects(width, height, world, rank, band_rows)
     for k, (x0, y0, w, h) in enumerate(mine):
         render_rect(x0, y0, w, h, packed[k, :h])
+    if comm_device is not None and torch.device(comm_device) != packed.device:
+        packed = packed.to(comm_device)
     parts = _gather_to_rank0(packed, world, rank, group)
     if rank != 0:
         return None
-    frame = torch.empty((height, width, 3), dtype=torch.float32, device=device)
+    frame = torch.empty((height, width, 3), dtype=torch.float32, device=packed.device)
     for r in range(world):
         for k, (x0, y0, w, h) in enumerate(band_rects(width, height, world, r, band_rows)):
             frame[y0:y0 + h] = parts[r][k, :h]
