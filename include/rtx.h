@@ -195,10 +195,13 @@ enum {
                                            tree with culling instead of through the
                                            library's own BVH (same results; for comparison) */
     RTX_FLAG_STAGE_TIMES     = 1u << 7, /* fill the per-stage ms_* fields of rtx_stats     */
-    RTX_FLAG_RENDER_WALK     = 1u << 8  /* rtx_trace_closest only: use the render path's
+    RTX_FLAG_RENDER_WALK     = 1u << 8, /* rtx_trace_closest only: use the render path's
                                            walk instead of the reference-order one; the
                                            leaf outputs and counters then describe that
                                            walk's own work, not the reference's            */
+    RTX_FLAG_SORT_MATERIAL   = 1u << 9  /* pathTrace levels are shaded in material order
+                                           (rays binned by the material they hit) instead
+                                           of queue order; same image                      */
 };
 
 /* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;

@@ -34,6 +34,7 @@ FLAG_REFERENCE_ORDER = 1 << 5
 FLAG_KD_CULLED = 1 << 6
 FLAG_STAGE_TIMES = 1 << 7
 FLAG_RENDER_WALK = 1 << 8
+FLAG_SORT_MATERIAL = 1 << 9
 
 # motion functions of the host API (Animatable.cpp:5-35), by rth_add_sphere code
 MOTION = {"noMovement": 0, "oscilateX": 1, "oscilateY": 2, "rotateY": 3,

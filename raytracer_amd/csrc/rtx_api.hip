@@ -71,6 +71,8 @@ struct Workspace {
     RayQueue q[2];
     ShadowQueue sq;
     uint32_t* shadow_index = nullptr;       // per ray: first shadow entry
+    uint32_t* perm = nullptr;               // shading order (material sort)
+    uint32_t* bins = nullptr;               // 2 * kBins: histogram, next free place per bin
     double* sample = nullptr;               // 3 per slot
     uint32_t* counts = nullptr;             // [0] next queue, [1] shadow queue, [2] generate
     unsigned long long* work = nullptr;     // 6 counters
@@ -81,6 +83,7 @@ struct Workspace {
         if (base) (void)hipFree(base);
         if (shadow_base_mem) (void)hipFree(shadow_base_mem);
         if (counts) (void)hipFree(counts);
+        if (bins) (void)hipFree(bins);
         if (work) (void)hipFree(work);
         if (host_counts) (void)hipHostFree(host_counts);
         if (host_work) (void)hipHostFree(host_work);
@@ -99,7 +102,7 @@ size_t queue_bytes(size_t cap)
 {
     auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
     size_t per_queue = 10 * al(cap * 8) + 4 * al(cap * 4) + al(cap * 4) + al(cap * 8);
-    return 2 * per_queue + al(cap * 4) + al(cap * 3 * 8);
+    return 2 * per_queue + 2 * al(cap * 4) + al(cap * 3 * 8);
 }
 
 }  // namespace
@@ -122,6 +125,8 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap)
     if (!w.counts) {
         HIP_TRY(hipMalloc(&w.counts, 4 * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&w.work, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&w.bins, 2 * kBins * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(w.bins, 0, 2 * kBins * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc(&w.host_counts, 4 * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc(&w.host_work, 8 * sizeof(unsigned long long)));
     }
@@ -140,6 +145,7 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap)
             q.hit_prim = carve<int32_t>(p, cap); q.hit_depth = carve<double>(p, cap);
         }
         w.shadow_index = carve<uint32_t>(p, cap);
+        w.perm = carve<uint32_t>(p, cap);
         w.sample = carve<double>(p, cap * 3);
         w.capacity = cap;
     }
@@ -693,7 +699,14 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 HIP_TRY(hipMemsetAsync(w.counts, 0, 2 * sizeof(uint32_t), st));
                 if (!whitted) {
                     timer.begin();
-                    hipLaunchKernelGGL(k_shade_path, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, nq, w.counts + 0, w.sample);
+                    const uint32_t* perm = nullptr;
+                    if (rd->flags & RTX_FLAG_SORT_MATERIAL) {
+                        hipLaunchKernelGGL(k_bin_count, grid_for(count), dim3(kBlock), 0, st, sc->d, q.hit_prim, count, w.bins);
+                        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBins), 0, st, w.bins);
+                        hipLaunchKernelGGL(k_bin_scatter, grid_for(count), dim3(kBlock), 0, st, sc->d, q.hit_prim, count, w.bins, w.perm);
+                        perm = w.perm;
+                    }
+                    hipLaunchKernelGGL(k_shade_path, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, perm, nq, w.counts + 0, w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                 } else {

@@ -708,18 +708,78 @@ RTX_DEV Rng ray_rng(const RenderParams& p, const RayQueue& q, uint32_t i, uint32
     return r;
 }
 
+// ---- shading order: rays binned by the material they hit --------------------------------------
+// The branches of pathTrace (refract / mirror / diffuse / emissive, textured or not) are
+// chosen by the material, so a wave whose rays all hit one material runs one of them.  A
+// counting sort over kBins keys (0 = miss, else 1 + material mod 63): count, scan, scatter
+// into a permutation; rays of a workgroup keep consecutive places within their bin, so the
+// shading kernel's gathers stay mostly contiguous.
+constexpr uint32_t kBins = 64;
+
+RTX_DEV uint32_t shade_bin(const DScene& s, int32_t prim)
+{
+    return prim < 0 ? 0u : 1u + s.prim_material[prim] % (kBins - 1u);
+}
+
+// bins[0 .. kBins) += histogram of the queue
+__global__ void __launch_bounds__(kBlock)
+k_bin_count(DScene s, const int32_t* __restrict__ hit_prim, uint32_t n, uint32_t* bins)
+{
+    __shared__ uint32_t h[kBins];
+    if (threadIdx.x < kBins) h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) atomicAdd(&h[shade_bin(s, hit_prim[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < kBins && h[threadIdx.x]) atomicAdd(bins + threadIdx.x, h[threadIdx.x]);
+}
+
+// one wave: bins[kBins + k] = first place of bin k; the histogram is cleared for the next level
+__global__ void __launch_bounds__(kBins)
+k_bin_scan(uint32_t* bins)
+{
+    __shared__ uint32_t c[kBins];
+    uint32_t k = threadIdx.x;
+    c[k] = bins[k];
+    __syncthreads();
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < k; ++j) sum += c[j];
+    bins[kBins + k] = sum;
+    bins[k] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_bin_scatter(DScene s, const int32_t* __restrict__ hit_prim, uint32_t n, uint32_t* bins, uint32_t* perm)
+{
+    __shared__ uint32_t h[kBins], base[kBins];
+    if (threadIdx.x < kBins) h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t key = 0, rank = 0;
+    if (i < n) { key = shade_bin(s, hit_prim[i]); rank = atomicAdd(&h[key], 1u); }
+    __syncthreads();
+    if (threadIdx.x < kBins) base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(bins + kBins + threadIdx.x, h[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (i < n) perm[base[key] + rank] = i;
+}
+
 // ---- pathTrace, one recursion level (Raytracer.cpp:217-355) -------------------------------------
 // The reference's result is `weight-product * terminal radiance`: refraction returns the
 // child's radiance unchanged (:272) and a bounce returns ctSpecular + kD*diffuse, both
 // linear in the child's radiance (:302-348).  Each ray therefore carries the product of
 // the per-level factors and the terminal value is added once to its sample.
+// `perm` (optional) lists the queue entries in the order they are to be shaded: thread j
+// shades ray perm[j].
 __global__ void __launch_bounds__(kBlock)
-k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, RayQueue next, uint32_t* next_count, double* sample)
+k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* __restrict__ perm, RayQueue next,
+             uint32_t* next_count, double* sample)
 {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t j0 = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = j0 < n;
+    const uint32_t i = live ? (perm ? perm[j0] : j0) : 0u;
     bool spawn = false;
     Ray child; d3 cw = mk(0, 0, 0); double cior = 1.0; uint32_t slot = 0, layer = 0, cbranch = 0, ccounter = 0;
-    if (i < n) {
+    if (live) {
         slot = q.slot[i]; layer = q.layer[i];
         d3 w = mk(q.wx[i], q.wy[i], q.wz[i]);
         d3 clear = ld3(p.d.clear_color);

@@ -195,3 +195,27 @@ def test_linear_scan_equals_kd_image(gpu):
     ref, _, _, _ = orc.render(desc, b)
     assert rel_err(ib, ref).max() < REL_TOL
     assert psnr(ia, ib) >= 60.0
+
+
+@pytest.mark.parametrize("name", ["live", "lens", "mesh_ggx"])
+def test_material_sorted_shading_gives_identical_images(gpu, name):
+    """RTX_FLAG_SORT_MATERIAL only changes the order in which a level's rays are shaded:
+    every path still adds its one terminal value to its own sample slot."""
+    if name == "live":
+        scene, cam = scenes.live_scene()
+    elif name == "lens":
+        scene, cam = scenes.lens_scene()
+    else:
+        scene, cam = scenes.mesh_scene(slices=60, stacks=30, ggx=True)
+        scene.sphere((0.0, 10.0, 0.0), 2.0, scene.material("PlainWhiteTees", emission=(8.0, 8.0, 8.0)))
+    desc = scene.frame(0.3)
+    imgs = []
+    with gpu.DeviceScene(desc) as ds:
+        for fl in (0, abi.FLAG_SORT_MATERIAL):
+            rd = scenes.render_desc(200, 120, integrator=abi.INTEGRATOR_PATH, camera=cam, n=2, max_depth=6, bias=1e-4,
+                                    flags=fl, passes=2)
+            img, st = ds.render(rd)
+            imgs.append((img, st.rays))
+    assert imgs[0][1] == imgs[1][1]
+    assert np.array_equal(imgs[0][0], imgs[1][0])
+    assert np.isfinite(imgs[0][0]).all() and imgs[0][0].max() > 0

@@ -60,6 +60,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("names", nargs="*", default=["c1", "c2", "c3", "c4w", "c4p"])
     ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--sort-material", action="store_true", help="shade pathTrace levels in material order")
     args = ap.parse_args()
     import torch
     from raytracer_amd import abi, device
@@ -93,7 +94,7 @@ def main():
                 host_s += time.perf_counter() - th
             fb.zero_()
             rd = rd_of(1 + f)
-            rd.flags |= abi.FLAG_STAGE_TIMES
+            rd.flags |= abi.FLAG_STAGE_TIMES | (abi.FLAG_SORT_MATERIAL if args.sort_material else 0)
             st = ds.render_device(rd, fb.data_ptr())
             for k in rays:
                 rays[k] += getattr(st, k)
@@ -102,7 +103,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0 - host_s
         total = sum(rays.values())
-        out = {"config": name, "resolution": [rd0.width, rd0.height], "spp": rd0.pixel_multisample_n ** 2,
+        out = {"config": name, "sort_material": args.sort_material, "resolution": [rd0.width, rd0.height], "spp": rd0.pixel_multisample_n ** 2,
                "shapes": desc.n_shapes, "kd": scene.kd_stats(), "frames": frames,
                **{k: v // frames for k, v in rays.items()},
                "Mrays_per_s": round(total / dt / 1e6, 1), "ms_per_frame": round(dt / frames * 1e3, 3),
