@@ -52,6 +52,7 @@ def lib():
     L.rth_kd_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.rth_scene_box.argtypes = [C.c_void_p, PD]
     L.rth_frame_timings.argtypes = [C.c_void_p, PD]
+    L.rth_set_kd_builder.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.rth_make_camera.argtypes = [PD, PD, C.c_double, C.POINTER(abi.Camera)]
     _lib = L
     return L
@@ -166,6 +167,12 @@ class HostScene:
             raise RuntimeError(self._L.rth_scene_error(self._h).decode())
         self.desc = p.contents
         return self.desc
+
+    def set_kd_builder(self, builder="flat", threads=0):
+        """'flat': the tree is built straight into the flattened arrays, on `threads` threads
+        (0 = automatic); 'reference': buildKDTree's KDNode objects and a flattening walk, as
+        the reference builds it.  Both give the same arrays."""
+        self._L.rth_set_kd_builder(self._h, {"flat": 0, "reference": 1}[builder], int(threads))
 
     def kd_stats(self):
         out = (C.c_uint32 * 5)()

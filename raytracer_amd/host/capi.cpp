@@ -23,6 +23,8 @@ struct rth_scene {
     AABB sceneBox;
     std::string error;
     double timings[4] = {0, 0, 0, 0};      // seconds: redoAABBs, buildKDTree, flatten, freeing the old tree
+    int builder = 0;                        // 0: buildFlatKD; 1: buildKDTree + flattening walk
+    int threads = 0;
 };
 
 static MovementFunction motionOf(int kind) {
@@ -170,9 +172,17 @@ const rtx_scene_desc* rth_frame(rth_scene* s, double current_time) {
         delete s->fi.kdTree;
         s->fi.kdTree = nullptr;
         double t2 = now();
-        s->fi.kdTree = buildKDTree(s->fi.shapes, s->sceneBox);
-        double t3 = now();
-        s->flat.build(s->fi);
+        double t3;
+        if (s->builder == 1) {
+            // the reference's own construction: KDNode objects, then the flattening walk
+            s->fi.kdTree = buildKDTree(s->fi.shapes, s->sceneBox);
+            t3 = now();
+            s->flat.build(s->fi);
+        } else {
+            // the same tree built straight into the flat arrays (timings[1] stays 0)
+            t3 = t2;
+            s->flat.build(s->fi, s->sceneBox, s->threads);
+        }
         double t4 = now();
         s->timings[0] = t1 - t0; s->timings[1] = t3 - t2; s->timings[2] = t4 - t3; s->timings[3] = t2 - t1;
         return &s->flat.desc();
@@ -181,6 +191,9 @@ const rtx_scene_desc* rth_frame(rth_scene* s, double current_time) {
         return nullptr;
     }
 }
+
+// builder 0: buildFlatKD (default), 1: buildKDTree + flattening walk; threads <= 0: automatic
+void rth_set_kd_builder(rth_scene* s, int builder, int threads) { s->builder = builder; s->threads = threads; }
 
 // branches, leaves, leaf refs, depth, largest leaf of the last rth_frame
 void rth_kd_stats(const rth_scene* s, uint32_t out[5]) {

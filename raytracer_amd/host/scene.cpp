@@ -340,12 +340,12 @@ struct Flattener {
         return (int32_t)id;
     }
 
-    void run() {
+    void run(const AABB* sceneBox, int threads) {
         const uint32_t nShapes = (uint32_t)fi.shapes.size();
         std::vector<const Biconvex*> lenses;
         for (uint32_t i = 0; i < nShapes; ++i) {
             const Shape* s = fi.shapes[i];
-            shapeId.emplace(s, i);
+            if (!sceneBox) shapeId.emplace(s, i);
             if (const Triangle* t = dynamic_cast<const Triangle*>(s)) {
                 uint32_t idx = (uint32_t)(out.triPos.size() / 9);
                 for (uint32_t v = 0; v < 3; ++v) {
@@ -371,15 +371,25 @@ struct Flattener {
             }
         }
         for (const Light* l : fi.lights) out.lights.push_back(l->flatten());
+        if (sceneBox) {
+            FlatKD kd;
+            buildFlatKD(fi.shapes, *sceneBox, kd, threads);
+            out.branchMin.swap(kd.bmin); out.branchMax.swap(kd.bmax); out.branchValue.swap(kd.value);
+            out.branchAxis.swap(kd.axis); out.branchLesser.swap(kd.lesser); out.branchGreater.swap(kd.greater);
+            out.leafFirst.swap(kd.leafFirst); out.leafCount.swap(kd.leafCount); out.leafRefs.swap(kd.leafRefs);
+            out.stats = kd.stats;
+            root = kd.root;
+            return;
+        }
         if (!fi.kdTree) throw std::runtime_error("FrameInfo::kdTree is null");
-        int32_t root = walk(fi.kdTree, 0);
+        root = walk(fi.kdTree, 0);
 
         out.stats.branches = (uint32_t)out.branchValue.size();
         out.stats.leaves = (uint32_t)out.leafFirst.size();
         out.stats.leafRefs = (uint32_t)out.leafRefs.size();
         out.stats.depth = maxDepth;
-        (void)root;
     }
+    int32_t root = 0;
 };
 
 }  // namespace
@@ -387,10 +397,21 @@ struct Flattener {
 void FlatScene::build(const FrameInfo& fi) {
     *this = FlatScene();
     Flattener f(*this, fi);
-    f.run();
+    f.run(nullptr, 0);
+    finish(fi, f.root);
+}
+
+void FlatScene::build(const FrameInfo& fi, const AABB& sceneBox, int threads) {
+    *this = FlatScene();
+    Flattener f(*this, fi);
+    f.run(&sceneBox, threads);
+    finish(fi, f.root);
+}
+
+void FlatScene::finish(const FrameInfo& fi, int32_t root) {
     std::memset(&d, 0, sizeof d);
     d.abi_version = RTX_ABI_VERSION;
-    d.kd_root = fi.kdTree->isLeaf ? ~(int32_t)0 : 0;   // preorder: the root is node 0 of its kind
+    d.kd_root = root;                                   // pre-order: node 0 of its kind
     d.n_branches = (uint32_t)branchValue.size();
     d.n_leaves = (uint32_t)leafFirst.size();
     d.n_leaf_refs = (uint32_t)leafRefs.size();

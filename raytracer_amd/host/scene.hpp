@@ -261,12 +261,29 @@ rtx_camera makeCamera(dvec3 eye, dvec3 lookat, double fovDegrees = 90.0);
 // ---- flattener -----------------------------------------------------------------
 struct KDStats { uint32_t branches = 0, leaves = 0, leafRefs = 0, depth = 0, maxLeaf = 0; };
 
+// The KD tree as the flattened arrays of rtx_scene_desc: branches and leaves numbered in
+// pre-order (lesser subtree first), child >= 0 branch, < 0 leaf ~child.
+struct FlatKD {
+    std::vector<double> bmin, bmax, value;          // bmin/bmax: 3 per branch
+    std::vector<int32_t> axis, lesser, greater;
+    std::vector<uint32_t> leafFirst, leafCount, leafRefs;
+    int32_t root = ~(int32_t)0;
+    KDStats stats;
+};
+
+// buildKDTree + flattening in one step: the same tree, built from compact records and on
+// several threads (threads <= 0: one per core, at most 16).  See kdbuild.cpp.
+void buildFlatKD(const std::vector<Shape*>& shapes, const AABB& box, FlatKD& out, int threads = 0);
+
 // Owns the SoA arrays an rtx_scene_desc points into.
 class FlatScene {
 public:
     // Walks fi.kdTree (which must have been built from fi.shapes at fi.currentTime)
     // and fills the arrays; throws std::runtime_error on an unsupported Shape subclass.
     void build(const FrameInfo& fi);
+    // The same with the tree built here by buildFlatKD from fi.shapes inside sceneBox
+    // (fi.kdTree is not used).
+    void build(const FrameInfo& fi, const AABB& sceneBox, int threads = 0);
     const rtx_scene_desc& desc() const { return d; }
     KDStats stats;
 
@@ -284,6 +301,7 @@ public:
     std::vector<uint8_t> texels;
     std::vector<rtx_light> lights;
 private:
+    void finish(const FrameInfo& fi, int32_t root);
     rtx_scene_desc d;
 };
 

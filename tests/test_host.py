@@ -125,3 +125,60 @@ def test_texture_and_sampler_descriptors():
     mat = desc.materials[0]
     assert mat.color_fn.kind == abi.SAMPLER_TEXTURE_VEC3 and mat.smoothness_fn.kind == abi.SAMPLER_DOUBLE_CHECKERS
     assert mat.ns_fn.kind == abi.SAMPLER_CONST
+
+
+def _kd_arrays(scene, desc):
+    from raytracer_amd import host
+    d = desc
+    out = {"root": d.kd_root, "stats": scene.kd_stats()}
+    for name, cnt, dt in (("branch_min", 3 * d.n_branches, np.float64), ("branch_max", 3 * d.n_branches, np.float64),
+                          ("branch_value", d.n_branches, np.float64), ("branch_axis", d.n_branches, np.int32),
+                          ("branch_lesser", d.n_branches, np.int32), ("branch_greater", d.n_branches, np.int32),
+                          ("leaf_first", d.n_leaves, np.uint32), ("leaf_count", d.n_leaves, np.uint32),
+                          ("leaf_refs", d.n_leaf_refs, np.uint32)):
+        out[name] = host.desc_array(d, name, cnt, dt).copy()
+    return out
+
+
+@pytest.mark.parametrize("name", ["live", "whitted", "lens", "mesh", "ties", "animated"])
+def test_flat_kd_builder_equals_buildkdtree(name):
+    """buildFlatKD (compact records, partial sorts, threads) must give exactly the arrays that
+    buildKDTree + the flattening walk give: same branches, same leaf contents in the same
+    order, same numbering, whatever the number of threads."""
+    from raytracer_amd import scenes, host
+
+    def make():
+        if name == "live":
+            return scenes.live_scene()[0], 0.7
+        if name == "whitted":
+            return scenes.whitted_scene()[0], 0.0
+        if name == "lens":
+            return scenes.lens_scene()[0], 0.0
+        if name == "mesh":
+            return scenes.mesh_scene(slices=80, stacks=40)[0], 0.0
+        if name == "animated":
+            return scenes.animated_scene(copies=2, slices=60, stacks=30), 1.3
+        # many exactly equal keys: duplicated shapes and an axis-aligned grid of quads
+        rng = np.random.default_rng(3)
+        s = host.HostScene()
+        m = s.material("PlainWhiteTees")
+        tri = rng.integers(-4, 5, size=(300, 3, 3)).astype(np.float64)
+        gx, gz = np.meshgrid(np.arange(-5.0, 5.0), np.arange(-5.0, 5.0))
+        quads = np.array([[[x, 0.0, z], [x + 1, 0.0, z], [x + 1, 0.0, z + 1]] for x, z in zip(gx.ravel(), gz.ravel())])
+        pos = np.concatenate([tri, tri, quads, quads[::-1]])
+        nrm = np.tile([0.0, 1.0, 0.0], (len(pos), 3, 1))
+        uv = np.zeros((len(pos), 3, 2))
+        s.triangles(pos, nrm, uv, m)
+        return s, 0.0
+
+    got = {}
+    for builder, threads in (("reference", 0), ("flat", 1), ("flat", 3), ("flat", 8)):
+        scene, t = make()
+        scene.set_kd_builder(builder, threads)
+        got[(builder, threads)] = _kd_arrays(scene, scene.frame(t))
+    ref = got[("reference", 0)]
+    for key, arrays in got.items():
+        for field, want in ref.items():
+            have = arrays[field]
+            same = np.array_equal(want, have) if isinstance(want, np.ndarray) else want == have
+            assert same, (key, field)
