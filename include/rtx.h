@@ -305,6 +305,23 @@ int rtx_render(rtx_scene* scene, const rtx_render_desc* desc, float* accum, rtx_
 int rtx_render_device(rtx_scene* scene, const rtx_render_desc* desc, float* accum_device,
                       rtx_stats* stats);
 
+/*
+ * The present step: what the reference does to drawBuffer between a pass and the PNG.
+ *   frameBuffer = drawBuffer / float(passes); with RTX_TONEMAP_CBRT each channel goes
+ *   through cbrt in FP32 (Raytracer.cpp:720-725; the Whitted variant shows the buffer as
+ *   is); the pass-through shaders draw it into an sRGB framebuffer (GL_FRAMEBUFFER_SRGB,
+ *   Raytracer.cpp:422: clamp to [0,1], sRGB transfer function, 8 bits); saveImage reads
+ *   the pixels back and writes them flipped (Raytracer.cpp:90-105).
+ * `accum` is a width*height*3 float buffer, row 0 = bottom row; `rgb8` receives
+ * width*height*3 bytes, with flip != 0 top row first (the PNG's order).  The _device form
+ * takes device pointers and runs on the scene's stream (returns after completion).
+ */
+enum { RTX_TONEMAP_NONE = 0, RTX_TONEMAP_CBRT = 1 };
+int rtx_present(rtx_scene* scene, const float* accum, uint32_t width, uint32_t height, uint32_t passes,
+                uint32_t tonemap, int flip, uint8_t* rgb8);
+int rtx_present_device(rtx_scene* scene, const float* accum_device, uint32_t width, uint32_t height,
+                       uint32_t passes, uint32_t tonemap, int flip, uint8_t* rgb8_device);
+
 /* The draw-index'th uniform of one sample's random stream, in [0,1]
  * (replaces rand()/RAND_MAX, Raytracer.cpp:65-67).  Exposed so a host-side
  * reference can be driven with identical samples. */

@@ -127,5 +127,16 @@ def camera_rays(rd, sub_sample=None):
     return o, d
 
 
+def present(accum, passes=1, tonemap=1, flip=True):
+    accum = np.ascontiguousarray(accum, dtype=np.float32)
+    h, w, _ = accum.shape
+    out = np.empty((h, w, 3), dtype=np.uint8)
+    L = lib()
+    L.orc_present.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint8)]
+    L.orc_present.restype = None
+    L.orc_present(accum.ctypes.data_as(C.POINTER(C.c_float)), w, h, passes, tonemap, int(flip), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
 def uniform(seed, frame, pixel, sample, branch, draw):
     return lib().orc_uniform(seed, frame, pixel, sample, branch, draw)

@@ -73,6 +73,24 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 
 /* uniform in [0,1] inclusive, like rand()/RAND_MAX (Raytracer.cpp:65-67) */
+/* frameBuffer[j] = drawBuffer[j] / float(i+1); cbrt per channel (Raytracer.cpp:720-725); the
+ * quad is drawn into an sRGB framebuffer (:422), read back as bytes and flipped (:102-103) */
+void orc_present(const float* accum, uint32_t width, uint32_t height, uint32_t passes, uint32_t tonemap,
+                 int flip, uint8_t* rgb8)
+{
+    for (uint32_t y = 0; y < height; ++y) {
+        uint32_t oy = flip ? height - 1u - y : y;
+        for (uint32_t k = 0; k < width * 3u; ++k) {
+            float v = accum[(size_t)y * width * 3u + k] / (float)passes;
+            if (tonemap) v = cbrtf(v);
+            if (!(v > 0.0f)) v = 0.0f;
+            if (v > 1.0f) v = 1.0f;
+            float e = v <= 0.0031308f ? 12.92f * v : 1.055f * powf(v, 1.0f / 2.4f) - 0.055f;
+            rgb8[(size_t)oy * width * 3u + k] = (uint8_t)(int)(e * 255.0f + 0.5f);
+        }
+    }
+}
+
 double orc_uniform(uint64_t seed, uint32_t frame, uint32_t pixel, uint32_t sample,
                    uint32_t branch, uint32_t draw_index)
 {

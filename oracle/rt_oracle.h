@@ -45,6 +45,11 @@ double orc_uniform(uint64_t seed, uint32_t frame, uint32_t pixel, uint32_t sampl
                    uint32_t branch, uint32_t draw_index);
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
+/* present step (Raytracer.cpp:720-725 cbrt in FP32 when tonemap != 0; :422 sRGB framebuffer;
+ * :103 vertical flip): accum is width*height*3 floats, row 0 = bottom; rgb8 gets the bytes */
+void orc_present(const float* accum, uint32_t width, uint32_t height, uint32_t passes, uint32_t tonemap,
+                 int flip, uint8_t* rgb8);
+
 /* ---- function-level entry points for known-answer tests ------------------ */
 void orc_ray_init(const double origin[3], const double dir[3], double out_dir[3], double out_inv[3]);
 int  orc_aabb_enter_exit(const double bmin[3], const double bmax[3], const double origin[3],

@@ -36,6 +36,8 @@ FLAG_STAGE_TIMES = 1 << 7
 FLAG_RENDER_WALK = 1 << 8
 FLAG_SORT_MATERIAL = 1 << 9
 
+TONEMAP_NONE, TONEMAP_CBRT = 0, 1
+
 # motion functions of the host API (Animatable.cpp:5-35), by rth_add_sphere code
 MOTION = {"noMovement": 0, "oscilateX": 1, "oscilateY": 2, "rotateY": 3,
           "circle0": 4, "circle1": 5, "circle2": 6}

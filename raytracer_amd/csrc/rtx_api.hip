@@ -787,6 +787,43 @@ int rtx_render(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rtx_stats
     return rc;
 }
 
+int rtx_present_device(rtx_scene* sc, const float* accum, uint32_t width, uint32_t height, uint32_t passes,
+                       uint32_t tonemap, int flip, uint8_t* rgb8)
+{
+    if (!sc || !accum || !rgb8) return fail(RTX_ERR_INVALID, "null argument");
+    if (width == 0 || height == 0 || (uint64_t)width * height * 3 > 0xffffffffull) return fail(RTX_ERR_INVALID, "bad frame size");
+    if (passes == 0 || tonemap > RTX_TONEMAP_CBRT) return fail(RTX_ERR_INVALID, "bad passes / tonemap");
+    size_t total = (size_t)width * height * 3;
+    hipLaunchKernelGGL(k_present, grid_for(total), dim3(kBlock), 0, sc->stream, accum, width, height, (float)passes, tonemap,
+                       flip ? 1u : 0u, rgb8);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    return RTX_OK;
+}
+
+int rtx_present(rtx_scene* sc, const float* accum, uint32_t width, uint32_t height, uint32_t passes, uint32_t tonemap,
+                int flip, uint8_t* rgb8)
+{
+    if (!sc || !accum || !rgb8) return fail(RTX_ERR_INVALID, "null argument");
+    size_t total = (size_t)width * height * 3;
+    if (total == 0) return fail(RTX_ERR_INVALID, "bad frame size");
+    float* d_accum = nullptr;
+    uint8_t* d_rgb = nullptr;
+    HIP_TRY(hipMalloc(&d_accum, total * sizeof(float)));
+    hipError_t e = hipMalloc(&d_rgb, total);
+    int rc = RTX_OK;
+    if (e == hipSuccess) e = hipMemcpy(d_accum, accum, total * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(RTX_ERR_DEVICE, "present upload: %s", hipGetErrorString(e));
+    if (rc == RTX_OK) rc = rtx_present_device(sc, d_accum, width, height, passes, tonemap, flip, d_rgb);
+    if (rc == RTX_OK) {
+        e = hipMemcpy(rgb8, d_rgb, total, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RTX_ERR_DEVICE, "present download: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_accum);
+    if (d_rgb) (void)hipFree(d_rgb);
+    return rc;
+}
+
 double rtx_uniform(uint64_t seed, uint32_t frame, uint32_t pixel, uint32_t sample, uint32_t branch, uint32_t draw_index)
 {
     // host evaluation of the device generator (same integer arithmetic)

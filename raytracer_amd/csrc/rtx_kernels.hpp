@@ -999,4 +999,28 @@ k_resolve(RenderParams p, const double* __restrict__ sample, float* accum)
     accum[at + 2] += (float)px.z;
 }
 
+// ---- present (Raytracer.cpp:720-725, :422, :90-105) ------------------------------------------------
+// linear float -> 8-bit sRGB as an sRGB framebuffer stores it: clamp, transfer function, round
+RTX_DEV uint8_t srgb8(float c)
+{
+    if (!(c > 0.0f)) c = 0.0f;              // also NaN -> 0, as framebuffer conversion does
+    if (c > 1.0f) c = 1.0f;
+    float e = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    return (uint8_t)(int)(e * 255.0f + 0.5f);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_present(const float* __restrict__ accum, uint32_t width, uint32_t height, float passes, uint32_t tonemap, uint32_t flip,
+          uint8_t* __restrict__ rgb8)
+{
+    uint32_t k = blockIdx.x * kBlock + threadIdx.x;          // one thread per channel value
+    uint32_t total = width * height * 3u;
+    if (k >= total) return;
+    float v = accum[k] / passes;
+    if (tonemap == RTX_TONEMAP_CBRT) v = cbrtf(v);
+    uint32_t row = k / (width * 3u), in_row = k - row * width * 3u;
+    uint32_t out_row = flip ? height - 1u - row : row;
+    rgb8[out_row * width * 3u + in_row] = srgb8(v);
+}
+
 }  // namespace rtx

@@ -19,7 +19,8 @@ PD = C.POINTER(C.c_double)
 
 # every symbol include/rtx.h declares
 EXPORTS = ["rtx_init", "rtx_device_count", "rtx_scene_create", "rtx_scene_set_stream", "rtx_scene_destroy",
-           "rtx_trace_closest", "rtx_render", "rtx_render_device", "rtx_uniform", "rtx_last_error"]
+           "rtx_trace_closest", "rtx_render", "rtx_render_device", "rtx_present", "rtx_present_device", "rtx_uniform",
+           "rtx_last_error"]
 
 
 class RtxError(RuntimeError):
@@ -45,6 +46,9 @@ def lib():
         C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
     L.rtx_render.argtypes = [C.c_void_p, C.POINTER(abi.RenderDesc), C.POINTER(C.c_float), C.POINTER(abi.Stats)]
     L.rtx_render_device.argtypes = [C.c_void_p, C.POINTER(abi.RenderDesc), C.c_void_p, C.POINTER(abi.Stats)]
+    L.rtx_present.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                              C.POINTER(C.c_uint8)]
+    L.rtx_present_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     L.rtx_uniform.restype = C.c_double
     L.rtx_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.rtx_last_error.restype = C.c_char_p
@@ -135,6 +139,21 @@ class DeviceScene:
         _check(self._L.rtx_render_device(self._h, C.byref(rd), C.c_void_p(accum_ptr),
                                          C.byref(stats) if want_stats else None))
         return stats
+
+
+    def present(self, accum, passes=1, tonemap=abi.TONEMAP_CBRT, flip=True):
+        """rtx_present: [H, W, 3] float accumulation buffer (row 0 = bottom) -> [H, W, 3] uint8 sRGB."""
+        accum = np.ascontiguousarray(accum, dtype=np.float32)
+        h, w, _ = accum.shape
+        out = np.empty((h, w, 3), dtype=np.uint8)
+        _check(self._L.rtx_present(self._h, accum.ctypes.data_as(C.POINTER(C.c_float)), w, h, passes, tonemap, int(flip),
+                                   out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def present_device(self, accum_ptr, width, height, rgb8_ptr, passes=1, tonemap=abi.TONEMAP_CBRT, flip=True):
+        """rtx_present_device on device memory."""
+        _check(self._L.rtx_present_device(self._h, C.c_void_p(accum_ptr), width, height, passes, tonemap, int(flip),
+                                          C.c_void_p(rgb8_ptr)))
 
 
 def uniform(seed, frame, pixel, sample, branch, draw):

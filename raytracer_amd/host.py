@@ -54,6 +54,7 @@ def lib():
     L.rth_frame_timings.argtypes = [C.c_void_p, PD]
     L.rth_set_kd_builder.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.rth_make_camera.argtypes = [PD, PD, C.c_double, C.POINTER(abi.Camera)]
+    L.rth_write_png.argtypes = [C.c_char_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
     _lib = L
     return L
 
@@ -189,6 +190,15 @@ class HostScene:
         out = (C.c_double * 6)()
         self._L.rth_scene_box(self._h, out)
         return np.array(out[:3]), np.array(out[3:])
+
+
+def write_png(path, rgb8):
+    """[H, W, 3] uint8, top row first -> PNG file (the stand-in for stbi_write_png, Raytracer.cpp:104)."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, c = rgb8.shape
+    assert c == 3
+    if lib().rth_write_png(os.fsencode(path), rgb8.ctypes.data_as(C.POINTER(C.c_uint8)), w, h) != 0:
+        raise OSError(f"cannot write {path}")
 
 
 def desc_array(desc, name, count, dtype):

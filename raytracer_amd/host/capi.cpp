@@ -210,6 +210,12 @@ void rth_scene_box(const rth_scene* s, double out[6]) {
     for (int i = 0; i < 3; ++i) { out[i] = s->sceneBox.min[i]; out[3 + i] = s->sceneBox.max[i]; }
 }
 
+// Headless stand-in for saveImage (Raytracer.cpp:90-105, stbi_write_png): 8-bit RGB rows, top
+// row first, into a PNG file (one zlib stream, filter 0 on every scanline).  0 on success.
+int rth_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+    return writePng(path, rgb8, width, height) ? 0 : -1;
+}
+
 // camera basis of Raytracer.cpp:642-660
 void rth_make_camera(const double* eye, const double* lookat, double fov_degrees, rtx_camera* out) {
     *out = makeCamera(v3(eye), v3(lookat), fov_degrees);

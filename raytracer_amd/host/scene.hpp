@@ -305,4 +305,8 @@ private:
     rtx_scene_desc d;
 };
 
+// ---- output ---------------------------------------------------------------------
+// PNG (RGB8, rows top first) through zlib; false when the file cannot be written.
+bool writePng(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+
 }  // namespace rth

@@ -219,3 +219,29 @@ def test_material_sorted_shading_gives_identical_images(gpu, name):
     assert imgs[0][1] == imgs[1][1]
     assert np.array_equal(imgs[0][0], imgs[1][0])
     assert np.isfinite(imgs[0][0]).all() and imgs[0][0].max() > 0
+
+
+def test_present_matches_oracle_and_writes_png(gpu, tmp_path):
+    """rtx_present (cbrt tonemap in FP32, sRGB framebuffer bytes, vertical flip) against the
+    oracle's restatement; device cbrtf/powf may differ from glibc's in the last bit, which can
+    move a value across a rounding boundary: at most one 8-bit step, on very few pixels."""
+    from PIL import Image
+    from raytracer_amd import output
+    scene, cam = scenes.live_scene()
+    desc = scene.frame(0.2)
+    rd = scenes.render_desc(160, 100, integrator=abi.INTEGRATOR_PATH, camera=cam, n=2, max_depth=4, bias=1e-4, passes=3)
+    with gpu.DeviceScene(desc) as ds:
+        img, _ = ds.render(rd)
+        edge = np.array([[[0.0, 1.0, 8.0], [-1.0, np.nan, 3 * 0.0031308]]], dtype=np.float32)
+        for accum, passes in ((img, 3), (edge, 3)):
+            for tonemap in (abi.TONEMAP_CBRT, abi.TONEMAP_NONE):
+                for flip in (True, False):
+                    got = ds.present(accum, passes=passes, tonemap=tonemap, flip=flip)
+                    want = orc.present(accum, passes=passes, tonemap=tonemap, flip=flip)
+                    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+                    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (diff.max(), (diff > 0).mean())
+        fw = output.FrameWriter(root=str(tmp_path / "out"))
+        path = fw.save(ds, 0, img, passes=3)
+        back = np.asarray(Image.open(path).convert("RGB"))
+        assert np.array_equal(back, ds.present(img, passes=3))
+        assert back.shape == (100, 160, 3) and back.max() > 50

@@ -1,5 +1,7 @@
 """Host scene API: KD construction (KDTree.cpp:68-126), flattening, and the oracle's KD walk
 against its own linear scan (the reference's KDTRACE toggle, Raytracer.cpp:114-118)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -182,3 +184,38 @@ def test_flat_kd_builder_equals_buildkdtree(name):
             have = arrays[field]
             same = np.array_equal(want, have) if isinstance(want, np.ndarray) else want == have
             assert same, (key, field)
+
+
+def test_png_writer_round_trip(tmp_path):
+    """rth_write_png output decodes (PIL) to the bytes handed in; FrameWriter names files as
+    the reference's OUTPUTFRAMES loop does."""
+    from PIL import Image
+    from raytracer_amd import host, output
+    rng = np.random.default_rng(9)
+    for (h, w) in ((1, 1), (7, 13), (120, 200)):
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        p = tmp_path / f"t_{h}x{w}.png"
+        host.write_png(str(p), img)
+        back = np.asarray(Image.open(p).convert("RGB"))
+        assert back.shape == img.shape and np.array_equal(back, img)
+    with pytest.raises(OSError):
+        host.write_png(str(tmp_path / "no_such_dir" / "x.png"), img)
+    fw = output.FrameWriter(root=str(tmp_path / "out"), stamp="2026-01-02-03-04-05")
+    assert fw.path(7).endswith(os.path.join("out", "2026-01-02-03-04-05", "7.png"))
+
+
+def test_oracle_present_known_values():
+    """sRGB framebuffer conversion of the present step on values with known encodings."""
+    from oracle import binding as orc
+    lin = np.array([[[0.0, 1.0, 0.5], [0.0031308, 0.2140411, -1.0], [2.0, np.nan, 1e-9]]], dtype=np.float32)
+    got = orc.present(lin, passes=1, tonemap=0, flip=False)
+    assert got[0, 0].tolist() == [0, 255, 188]
+    assert got[0, 1].tolist() == [10, 127, 0]
+    assert got[0, 2].tolist() == [255, 0, 0]
+    # cbrt tonemap, 2 passes: cbrt(0.25 / 2) = 0.5 -> 188
+    got = orc.present(np.full((2, 1, 3), 0.25, dtype=np.float32), passes=2, tonemap=1)
+    assert (got == 188).all()
+    # vertical flip
+    rows = np.zeros((2, 1, 3), dtype=np.float32); rows[1] = 1.0
+    assert orc.present(rows, tonemap=0, flip=True)[0, 0, 0] == 255
+    assert orc.present(rows, tonemap=0, flip=False)[0, 0, 0] == 0
