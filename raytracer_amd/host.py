@@ -54,6 +54,9 @@ def lib():
     L.rth_frame_timings.argtypes = [C.c_void_p, PD]
     L.rth_set_kd_builder.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.rth_make_camera.argtypes = [PD, PD, C.c_double, C.POINTER(abi.Camera)]
+    L.rth_add_model.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, PD, PD, C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.rth_fbx_probe.restype = C.c_long
+    L.rth_fbx_probe.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.rth_write_png.argtypes = [C.c_char_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
     _lib = L
     return L
@@ -134,6 +137,30 @@ class HostScene:
         assert normal.size == n * 9 and uv.size == n * 6
         return self._check(self._L.rth_add_triangles(self._h, pp, pn, pu, n, material))
 
+    def model(self, models_root, modelname, pos=(0.0, 0.0, 0.0), rotation=(0.0, 0.0, 0.0), material=None,
+              load_textures=True):
+        """addModel(shapes, modelname, pos, rot) (Raytracer.cpp:362-366): the triangles of
+        <models_root>/<modelname>/<modelname>.fbx.  With `material` every triangle gets it;
+        otherwise the model's own materials are used, their diffuse textures decoded here
+        (PIL) when load_textures is set and the files exist.  Returns (first shape, count)."""
+        path = os.path.join(models_root, modelname, modelname + ".fbx")
+        n, names = fbx_probe(path)
+        ids = []
+        if material is None and load_textures:
+            for name in names:
+                tex = -1
+                f = os.path.join(models_root, modelname, name) if name else None
+                if f and os.path.exists(f):
+                    from PIL import Image
+                    tex = self.texture(np.asarray(Image.open(f).convert("RGB")))
+                ids.append(tex)
+        arr = (C.c_int * max(len(ids), 1))(*ids) if ids else None
+        _, pp = _d(pos)
+        _, pr = _d(rotation)
+        first = self._check(self._L.rth_add_model(self._h, os.fsencode(models_root), modelname.encode(), pp, pr,
+                                                  -1 if material is None else material, arr, len(ids)))
+        return first, n
+
     def sphere(self, origin, radius, material, motion="noMovement"):
         _, po = _d(origin)
         return self._check(self._L.rth_add_sphere(self._h, po, float(radius), material, abi.MOTION[motion]))
@@ -190,6 +217,16 @@ class HostScene:
         out = (C.c_double * 6)()
         self._L.rth_scene_box(self._h, out)
         return np.array(out[:3]), np.array(out[3:])
+
+
+def fbx_probe(path):
+    """(triangles after triangulation, diffuse texture file name per material slot) of a binary FBX file."""
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().rth_fbx_probe(os.fsencode(path), buf, len(buf))
+    if n < 0:
+        raise RuntimeError(buf.value.decode(errors="replace"))
+    text = buf.value.decode(errors="replace")
+    return n, text.split("\n")[:-1] if text else []
 
 
 def write_png(path, rgb8):

@@ -18,6 +18,7 @@ struct rth_scene {
     std::vector<std::unique_ptr<Texture>> textures;
     std::vector<std::unique_ptr<Shape>> shapes;
     std::vector<std::unique_ptr<Light>> lights;
+    std::vector<std::unique_ptr<Model>> models;
     FrameInfo fi;
     FlatScene flat;
     AABB sceneBox;
@@ -124,6 +125,55 @@ int rth_add_triangles(rth_scene* s, const double* position, const double* normal
         }
         return first;
     })
+}
+
+// addModel (Raytracer.cpp:362-366): Model(modelname, pos, rot), its triangles appended to the
+// shapes.  material >= 0: every triangle gets that material; material < 0: the model's own
+// materials, where slot k samples scene texture texture_ids[k] when that is >= 0 (slot order
+// = rth_fbx_texture_names).  Returns the index of the first triangle added.
+int rth_add_model(rth_scene* s, const char* models_root, const char* modelname, const double* pos, const double* rot,
+                  int material, const int* texture_ids, int n_texture_ids) {
+    RTH_TRY(s, {
+        int next = 0;
+        auto loader = [&](const std::string&) -> Texture* {
+            int slot = next++;
+            if (!texture_ids || slot >= n_texture_ids || texture_ids[slot] < 0) return nullptr;
+            return s->textures.at((size_t)texture_ids[slot]).get();
+        };
+        std::unique_ptr<Model> m(new Model(models_root, modelname, pos ? v3(pos) : dvec3(0.0), rot ? v3(rot) : dvec3(0.0),
+                                           loader));
+        int first = (int)s->shapes.size();
+        Material* forced = material >= 0 ? s->materials.at((size_t)material).get() : nullptr;
+        for (size_t i = 0; i < m->owned.size(); ++i) {
+            if (forced) {
+                Triangle* t = m->owned[i].get();
+                s->shapes.emplace_back(new Triangle((*t)[0], (*t)[1], (*t)[2], forced));
+            } else {
+                s->shapes.emplace_back(m->owned[i].release());
+            }
+        }
+        m->owned.clear();
+        m->children.clear();
+        s->models.push_back(std::move(m));
+        return first;
+    })
+}
+
+// Diffuse texture file names of an FBX file's materials, one per line in slot order (an empty
+// line: no texture), into `out`; returns the number of triangles in the file, -1 on error
+// (message in `out`).
+long rth_fbx_probe(const char* path, char* out, size_t out_len) {
+    try {
+        FbxMesh mesh;
+        loadFbx(path, dmat4(1.0), mesh);
+        std::string names;
+        for (const std::string& f : mesh.materialTextures) { names += f; names += '\n'; }
+        if (out && out_len) { std::strncpy(out, names.c_str(), out_len - 1); out[out_len - 1] = 0; }
+        return (long)mesh.material.size();
+    } catch (const std::exception& e) {
+        if (out && out_len) { std::strncpy(out, e.what(), out_len - 1); out[out_len - 1] = 0; }
+        return -1;
+    }
 }
 
 int rth_add_sphere(rth_scene* s, const double* origin, double radius, int material, int motion) {

@@ -13,6 +13,9 @@
 //   FrameInfo (Raytracer.hpp:60-67 + lights, Raytracer-Noah-Desktop.cpp:104-111),
 //   redoAABBs (Raytracer.cpp:368-375).
 #pragma once
+#include <functional>
+#include <memory>
+#include <string>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -303,6 +306,34 @@ public:
 private:
     void finish(const FrameInfo& fi, int32_t root);
     rtx_scene_desc d;
+};
+
+// ---- Model (Model.hpp / Model.cpp) ------------------------------------------------
+// Triangle soup of a binary FBX file as the reference's importer settings produce it
+// (see fbx.cpp): 9 doubles of position and of normal and 6 of uv per triangle, and the
+// slot of the triangle's material in materialTextures (-1: the mesh has no material).
+struct FbxMesh {
+    std::vector<double> position, normal, uv;
+    std::vector<int32_t> material;
+    std::vector<std::string> materialTextures;      // per slot: file name of the diffuse texture, or empty
+};
+void loadFbx(const std::string& path, const dmat4& modelTransform, FbxMesh& out);
+
+// Model(modelname, pos, rotation) of Model.cpp:19-30; the file is
+// <modelsRoot>/<modelname>/<modelname>.fbx.  textureLoader maps a texture path to a decoded
+// Texture (or nullptr when it cannot be had; the material is then constant white).
+class Model {
+public:
+    Model(const std::string& modelsRoot, const std::string& modelname, dvec3 pos, dvec3 rotation,
+          const std::function<Texture*(const std::string&)>& textureLoader = nullptr);
+    std::vector<Triangle*> children;                        // Model.hpp: the mesh's triangles
+    std::vector<std::unique_ptr<Material>> modelMaterials;
+    std::vector<std::unique_ptr<Triangle>> owned;           // storage behind `children`
+    dmat4 transform;
+    std::string directory;
+    FbxMesh mesh;
+private:
+    std::unique_ptr<Material> fallback;
 };
 
 // ---- output ---------------------------------------------------------------------

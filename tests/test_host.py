@@ -219,3 +219,81 @@ def test_oracle_present_known_values():
     rows = np.zeros((2, 1, 3), dtype=np.float32); rows[1] = 1.0
     assert orc.present(rows, tonemap=0, flip=True)[0, 0, 0] == 255
     assert orc.present(rows, tonemap=0, flip=False)[0, 0, 0] == 0
+
+
+def test_fbx_reader_on_fixture():
+    """tests/golden/pyramid.fbx (written by tests/golden/make_fbx_fixture.py): quad base +
+    4 triangles, deflated vertex array, Model node with Rx(-90), x100 scaling, translation."""
+    from raytracer_amd import host
+    here = os.path.dirname(os.path.abspath(__file__))
+    n, names = host.fbx_probe(os.path.join(here, "golden", "pyramid.fbx"))
+    assert n == 6 and names == ["stone.png"]
+    # Model wants <root>/<name>/<name>.fbx: golden/pyramid.fbx is reached as root=tests, name=golden -> use a link-free copy
+    import shutil, tempfile
+    with tempfile.TemporaryDirectory() as root:
+        os.makedirs(os.path.join(root, "pyramid"))
+        shutil.copy(os.path.join(here, "golden", "pyramid.fbx"), os.path.join(root, "pyramid", "pyramid.fbx"))
+        s = HostScene()
+        white = s.material("PlainWhiteTees")
+        first, count = s.model(root, "pyramid", material=white)
+        assert (first, count) == (0, 6)
+        s2 = HostScene()
+        first2, _ = s2.model(root, "pyramid", pos=(1.0, 2.0, 3.0))          # own materials, texture file absent
+        d2 = s2.frame(0.0)
+        assert d2.n_triangles == 6 and d2.n_materials == 1
+        moved = desc_array(d2, "tri_position", 54, np.float64).reshape(6, 3, 3)
+    d = s.frame(0.0)
+    pos = desc_array(d, "tri_position", 54, np.float64).reshape(6, 3, 3)
+    nrm = desc_array(d, "tri_normal", 54, np.float64).reshape(6, 3, 3)
+    uv = desc_array(d, "tri_uv", 36, np.float64).reshape(6, 3, 2)
+    V = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], [0, 0, 1.5]], dtype=np.float64)
+    UV = np.array([[0, 0], [1, 0], [1, 1], [0, 1], [0.5, 0.25]], dtype=np.float64)
+    tris = [(3, 2, 1), (3, 1, 0), (0, 1, 4), (1, 2, 4), (2, 3, 4), (3, 0, 4)]      # fans of the five polygons
+    for t, idx in enumerate(tris):
+        for k, v in enumerate(idx):
+            x, y, z = V[v]
+            want = np.array([x, z + 0.5, -y])           # Rx(-90), scale 100 * 0.01, translation 50 * 0.01
+            assert np.allclose(pos[t, k], want, atol=1e-6), (t, k, pos[t, k], want)
+            assert np.allclose(uv[t, k], [UV[v][0], 1.0 - UV[v][1]], atol=1e-7)
+            assert abs(np.linalg.norm(nrm[t, k]) - 1.0) < 1e-6
+        g = np.cross(pos[t, 1] - pos[t, 0], pos[t, 2] - pos[t, 0])
+        for k in range(3):
+            # smooth normals stay on the side faces' side (at the base's sharp rim they lean
+            # away from the base's own normal: every face at a position counts, whatever the angle)
+            assert t < 2 or np.dot(g, nrm[t, k]) > 0.0
+    # the apex normal is shared by the four side faces: straight up after the rotation
+    assert np.allclose(nrm[2, 2], [0.0, 1.0, 0.0], atol=1e-6)
+    # Model transform (Model.cpp:19-25): translation applied before the node matrix
+    assert np.allclose(moved, pos + np.array([1.0, 2.0, 3.0]), atol=1e-5)
+
+
+REFERENCE_MODELS = "/root/reference/Raytracer/Models"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_MODELS), reason="the reference's model files are not on this machine")
+def test_fbx_reference_models_triangle_counts():
+    """Triangle counts after triangulation of the reference's FBX files (data files, read in
+    place), as recorded when the reference was surveyed."""
+    from raytracer_amd import host
+    want = {"teapot": 15704, "bunny": 30338, "backpack": 67908, "lemon": 8298, "brick": 12, "cube": 12,
+            "brick2": 72, "shapes": 92}
+    for name, count in want.items():
+        n, names = host.fbx_probe(os.path.join(REFERENCE_MODELS, name, name + ".fbx"))
+        assert n == count, (name, n)
+    s = HostScene()
+    first, n = s.model(REFERENCE_MODELS, "teapot", material=s.material("PlainWhiteTees"))
+    s.point_light((5.0, 5.0, 5.0))
+    d = s.frame(0.0)
+    assert d.n_triangles == 15704
+    pos = desc_array(d, "tri_position", 9 * n, np.float64).reshape(-1, 3)
+    nrm = desc_array(d, "tri_normal", 9 * n, np.float64).reshape(-1, 3)
+    assert np.isfinite(pos).all() and np.isfinite(nrm).all()
+    assert np.abs(np.linalg.norm(nrm, axis=1) - 1.0).max() < 1e-5
+    lo, hi = pos.min(axis=0), pos.max(axis=0)
+    assert (hi - lo).max() < 1e4 and (hi - lo).min() > 1e-3
+    # and it renders: rays from a camera looking at the model's centre hit it
+    cam = __import__("raytracer_amd.host", fromlist=["make_camera"]).make_camera(tuple((lo + hi) / 2 + np.array([0, 0, 2.5 * (hi - lo).max()])), tuple((lo + hi) / 2))
+    rd = scenes.render_desc(48, 36, camera=cam, max_depth=1)
+    o, dd = camera_rays_np(rd)
+    got = orc.trace_closest(d, o, dd)
+    assert (got["prim"] >= 0).mean() > 0.1
