@@ -292,7 +292,7 @@ def test_fbx_reference_models_triangle_counts():
     lo, hi = pos.min(axis=0), pos.max(axis=0)
     assert (hi - lo).max() < 1e4 and (hi - lo).min() > 1e-3
     # and it renders: rays from a camera looking at the model's centre hit it
-    cam = __import__("raytracer_amd.host", fromlist=["make_camera"]).make_camera(tuple((lo + hi) / 2 + np.array([0, 0, 2.5 * (hi - lo).max()])), tuple((lo + hi) / 2))
+    cam = __import__("raytracer_amd.host", fromlist=["make_camera"]).make_camera(tuple((lo + hi) / 2 + np.array([0, 0, 1.1 * (hi - lo).max()])), tuple((lo + hi) / 2))
     rd = scenes.render_desc(48, 36, camera=cam, max_depth=1)
     o, dd = camera_rays_np(rd)
     got = orc.trace_closest(d, o, dd)
