@@ -19,6 +19,8 @@
 #include <vector>
 
 #include "rtx_kernels.hpp"
+#include <future>
+
 #include "rtx_bvh.hpp"
 
 using namespace rtx;
@@ -340,6 +342,16 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
         info[i] = (uint32_t)s->prim_type[i] | (s->prim_index[i] << 2);
     }
 
+    // the candidate BVH depends on the shape boxes alone: built on another thread while this
+    // one derives the tables that hang off the KD tree
+    if (s->n_shapes > kBvhMaxShapes) {
+        delete sc;
+        return fail(RTX_ERR_LIMIT, "%u shapes: the candidate BVH addresses at most %u", s->n_shapes, kBvhMaxShapes);
+    }
+    BvhBuild bvh;
+    std::future<void> bvh_done = std::async(std::launch::async, [&]() { build_bvh(boxes, s->n_shapes, bvh); });
+    struct Join { std::future<void>& f; ~Join() { if (f.valid()) f.wait(); } } join_bvh{bvh_done};
+
     // content boxes for the culled walk: per leaf the union of its shape boxes, per branch
     // the union of its children's (an empty leaf gets an inverted box that no ray hits)
     std::vector<PrimBox> leaf_cbox(s->n_leaves), branch_cbox(s->n_branches);
@@ -454,12 +466,7 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
         }
         prim_lca[p] = node;
     }
-    if (s->n_shapes > kBvhMaxShapes) {
-        delete sc;
-        return fail(RTX_ERR_LIMIT, "%u shapes: the candidate BVH addresses at most %u", s->n_shapes, kBvhMaxShapes);
-    }
-    BvhBuild bvh;
-    build_bvh(boxes, s->n_shapes, bvh);
+    bvh_done.get();
     std::vector<BvhPrim> bvh_prims(bvh.prims.size());
     for (size_t i = 0; i < bvh.prims.size(); ++i) {
         BvhPrim& q = bvh_prims[i];

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <future>
+#include <thread>
 #include <limits>
 #include <numeric>
 #include <vector>
@@ -54,9 +56,9 @@ struct Builder {
     const std::vector<PrimBox>& boxes;
     std::vector<double> centroid;       // 3 per prim
     std::vector<uint32_t> order;
-    BvhBuild& out;
+    int spawn_depth = 0;                // levels (from the root) that may hand a subtree to another thread
 
-    Builder(const std::vector<PrimBox>& b, uint32_t n, BvhBuild& o) : boxes(b), centroid(3 * (size_t)n), order(n), out(o)
+    Builder(const std::vector<PrimBox>& b, uint32_t n) : boxes(b), centroid(3 * (size_t)n), order(n)
     {
         for (uint32_t i = 0; i < n; ++i)
             for (int k = 0; k < 3; ++k) centroid[3 * (size_t)i + k] = 0.5 * (b[i].bmin[k] + b[i].bmax[k]);
@@ -70,7 +72,7 @@ struct Builder {
         return b;
     }
 
-    int32_t make_leaf(uint32_t lo, uint32_t hi)
+    static int32_t make_leaf_in(BvhBuild& out, const std::vector<uint32_t>& order, uint32_t lo, uint32_t hi)
     {
         uint32_t code = (uint32_t)out.prims.size() << 3 | (hi - lo - 1);
         for (uint32_t i = lo; i < hi; ++i) out.prims.push_back(order[i]);
@@ -133,16 +135,43 @@ struct Builder {
         return mid;
     }
 
-    int32_t build(uint32_t lo, uint32_t hi, int depth)
+    // appends a separately built subtree (disjoint range of `order`), renumbering it
+    static int32_t splice(BvhBuild& out, const BvhBuild& sub, int32_t sub_root)
+    {
+        const int32_t node_off = (int32_t)out.nodes.size();
+        const uint32_t prim_off = (uint32_t)out.prims.size();
+        auto moved = [&](int32_t c) {
+            if (c >= 0) return c + node_off;
+            uint32_t code = (uint32_t)~c;
+            return ~(int32_t)((((code >> 3) + prim_off) << 3) | (code & 7u));
+        };
+        for (BvhNode n : sub.nodes) { n.left = moved(n.left); n.right = moved(n.right); out.nodes.push_back(n); }
+        out.prims.insert(out.prims.end(), sub.prims.begin(), sub.prims.end());
+        out.depth = std::max(out.depth, sub.depth);
+        return moved(sub_root);
+    }
+
+    int32_t build(BvhBuild& out, uint32_t lo, uint32_t hi, int depth)
     {
         out.depth = std::max(out.depth, depth);
-        if (hi - lo <= kBvhLeafSize) return make_leaf(lo, hi);
+        if (hi - lo <= kBvhLeafSize) return make_leaf_in(out, order, lo, hi);
         uint32_t mid = split(lo, hi, depth);
         uint32_t id = (uint32_t)out.nodes.size();
         out.nodes.emplace_back();
         Box l = bounds(lo, mid), r = bounds(mid, hi);
-        int32_t left = build(lo, mid, depth + 1);
-        int32_t right = build(mid, hi, depth + 1);
+        int32_t left, right;
+        if (depth < spawn_depth && hi - lo >= 8192) {
+            // the two halves of `order` are disjoint: the left one is built on another thread
+            BvhBuild lsub, rsub;
+            auto fut = std::async(std::launch::async, [&]() { return build(lsub, lo, mid, depth + 1); });
+            int32_t rroot = build(rsub, mid, hi, depth + 1);
+            int32_t lroot = fut.get();
+            left = splice(out, lsub, lroot);
+            right = splice(out, rsub, rroot);
+        } else {
+            left = build(out, lo, mid, depth + 1);
+            right = build(out, mid, hi, depth + 1);
+        }
         BvhNode& n = out.nodes[id];
         std::memset(&n, 0, sizeof n);
         for (int k = 0; k < 3; ++k) {
@@ -160,9 +189,12 @@ inline void build_bvh(const std::vector<PrimBox>& boxes, uint32_t n_shapes, BvhB
 {
     out = BvhBuild();
     if (n_shapes == 0 || n_shapes > kBvhMaxShapes) { out.root = kBvhEmpty; return; }
-    bvh_detail::Builder b(boxes, n_shapes, out);
+    bvh_detail::Builder b(boxes, n_shapes);
+    unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    while ((1u << b.spawn_depth) < threads) ++b.spawn_depth;
+    if (threads > 1) b.spawn_depth += 1;
     out.nodes.reserve(n_shapes / 2 + 1);
-    out.root = b.build(0, n_shapes, 0);
+    out.root = b.build(out, 0, n_shapes, 0);
 }
 
 }  // namespace rtx

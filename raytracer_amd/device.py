@@ -12,7 +12,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.path.join(_HERE, "csrc", "librtx_hip.so")
+# RTX_HIP_LIB names another build of the library (kernel experiments)
+HIP_LIB = os.environ.get("RTX_HIP_LIB") or os.path.join(_HERE, "csrc", "librtx_hip.so")
 _lib = None
 
 PD = C.POINTER(C.c_double)
