@@ -15,6 +15,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def gpu():
     """Initialise the HIP library on device 0; fails loudly when there is no usable GPU."""
+    # PyTorch ships its own copy of the HIP runtime: when both live in one process torch has to
+    # be loaded first, or its later initialisation finds no device
+    import torch
+    torch.cuda.is_available()
     from raytracer_amd import device
     device.init(0)
     return device

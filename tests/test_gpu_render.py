@@ -245,3 +245,44 @@ def test_present_matches_oracle_and_writes_png(gpu, tmp_path):
         back = np.asarray(Image.open(path).convert("RGB"))
         assert np.array_equal(back, ds.present(img, passes=3))
         assert back.shape == (100, 160, 3) and back.max() > 50
+
+
+def test_full_size_bench_workload_properties(gpu):
+    """The bench workload at its full size (60 026 triangles, 1920x1080, Whitted + directional
+    light), where the CPU oracle would take minutes: size-independent properties instead.
+    The three walks must give the same image bit for bit and the same ray counts; four tiles
+    rendered separately must compose to the whole frame; a second pass must add exactly the
+    first pass's image again (no random numbers on this path)."""
+    import torch
+    scene, _ = scenes.mesh_scene()
+    desc = scene.frame(0.0)
+    cam = scenes.orbit_camera(0.4)
+    W, H = 1920, 1080
+
+    def rd(flags=0, tile=None, passes=1):
+        return scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=1, max_depth=3, bias=1e-2,
+                                  clear=(0.21, 0.78, 0.95), flags=flags, tile=tile, passes=passes)
+
+    with gpu.DeviceScene(desc) as ds:
+        fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        st_bvh = ds.render_device(rd(), fb.data_ptr())
+        img_bvh = fb.clone()
+        for flags in (abi.FLAG_REFERENCE_ORDER, abi.FLAG_KD_CULLED):
+            fb.zero_()
+            st = ds.render_device(rd(flags), fb.data_ptr())
+            assert (st.rays_primary, st.rays_shadow) == (st_bvh.rays_primary, st_bvh.rays_shadow)
+            assert torch.equal(fb, img_bvh)
+        assert st_bvh.rays_primary == W * H and 0 < st_bvh.rays_shadow < W * H
+        # tiles
+        whole = torch.zeros_like(img_bvh)
+        for (x0, y0) in ((0, 0), (960, 0), (0, 536), (960, 536)):
+            w, h = 960, (536 if y0 == 0 else H - 536)
+            part = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+            ds.render_device(rd(tile=(x0, y0, w, h)), part.data_ptr())
+            whole[y0:y0 + h, x0:x0 + w] = part
+        assert torch.equal(whole, img_bvh)
+        # passes accumulate in FP32, pass by pass
+        fb.zero_()
+        ds.render_device(rd(passes=2), fb.data_ptr())
+        assert torch.equal(fb, img_bvh + img_bvh)
+        assert torch.isfinite(img_bvh).all() and float(img_bvh.max()) > 0.5
