@@ -77,7 +77,7 @@ struct Workspace {
     uint32_t* bins = nullptr;               // 2 * kBins: histogram, next free place per bin
     double* sample = nullptr;               // 3 per slot
     uint32_t* counts = nullptr;             // [0] next queue, [1] shadow queue, [2] generate
-    unsigned long long* work = nullptr;     // 6 counters
+    unsigned long long* work = nullptr;     // 8 work counters + the shadow rays of single-level frames
     uint32_t* host_counts = nullptr;        // pinned
     unsigned long long* host_work = nullptr;
     ~Workspace()
@@ -117,6 +117,7 @@ struct rtx_scene {
     int device = 0;
     uint32_t kd_depth = 0;
     uint32_t bvh_depth = 0;
+    bool may_refract = false;       // some material can have transparency != 0 (rayTrace spawns a child then)
 };
 
 namespace {
@@ -126,11 +127,11 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap)
     Workspace& w = sc->ws;
     if (!w.counts) {
         HIP_TRY(hipMalloc(&w.counts, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&w.work, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&w.work, 9 * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc(&w.bins, 2 * kBins * sizeof(uint32_t)));
         HIP_TRY(hipMemset(w.bins, 0, 2 * kBins * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc(&w.host_counts, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc(&w.host_work, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipHostMalloc(&w.host_work, 9 * sizeof(unsigned long long)));
     }
     if (cap > w.capacity) {
         if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.capacity = 0; }
@@ -348,6 +349,8 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
         delete sc;
         return fail(RTX_ERR_LIMIT, "%u shapes: the candidate BVH addresses at most %u", s->n_shapes, kBvhMaxShapes);
     }
+    for (uint32_t i = 0; i < s->n_materials; ++i)
+        if (s->materials[i].transparency != 0.0 || s->materials[i].transparency_fn.kind != RTX_SAMPLER_CONST) sc->may_refract = true;
     BvhBuild bvh;
     std::future<void> bvh_done = std::async(std::launch::async, [&]() { build_bvh(boxes, s->n_shapes, bvh); });
     struct Join { std::future<void>& f; ~Join() { if (f.valid()) f.wait(); } } join_bvh{bvh_done};
@@ -675,6 +678,8 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, st)); }
     if (count_work) HIP_TRY(hipMemsetAsync(w.work, 0, 8 * sizeof(unsigned long long), st));
+    const bool single_level = whitted && !sc->may_refract && !(rd->flags & RTX_FLAG_WHITTED_REFLECT);
+    if (single_level) HIP_TRY(hipMemsetAsync(w.work + 8, 0, sizeof(unsigned long long), st));
 
     for (uint32_t pass = rd->first_pass; pass < rd->first_pass + rd->passes; ++pass) {
         p.pass = pass;
@@ -740,6 +745,14 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                 }
+                if (single_level) {
+                    // rayTrace spawns nothing when no material refracts and the mirror extension is
+                    // off: this level is the last one and the host need not wait to learn that.
+                    // The shadow-ray count is summed on the device and read with the frame's end.
+                    hipLaunchKernelGGL(k_add_count, dim3(1), dim3(1), 0, st, w.counts + 1, w.work + 8);
+                    HIP_TRY(hipGetLastError());
+                    break;
+                }
                 // one readback per level: next queue length and (Whitted) shadow rays traced
                 HIP_TRY(hipMemcpyAsync(w.host_counts, w.counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
@@ -757,8 +770,10 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     if (count_work) {
         HIP_TRY(hipMemcpyAsync(w.host_work, w.work, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     }
+    if (single_level) HIP_TRY(hipMemcpyAsync(w.host_work + 8, w.work + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (stats) HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (single_level) local.rays_shadow += w.host_work[8];
     if (stats) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));

@@ -999,6 +999,9 @@ k_resolve(RenderParams p, const double* __restrict__ sample, float* accum)
     accum[at + 2] += (float)px.z;
 }
 
+// total += *count (one thread): keeps a per-level counter's value when the host does not read it
+__global__ void k_add_count(const uint32_t* count, unsigned long long* total) { *total += *count; }
+
 // ---- present (Raytracer.cpp:720-725, :422, :90-105) ------------------------------------------------
 // linear float -> 8-bit sRGB as an sRGB framebuffer stores it: clamp, transfer function, round
 RTX_DEV uint8_t srgb8(float c)
