@@ -57,7 +57,12 @@ RTX_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-struct Rng { uint64_t seed; uint32_t frame, pixel, sample, branch, counter; };
+// One Philox block yields four consecutive draws: the block of the last draw is kept.
+struct Rng {
+    uint64_t seed; uint32_t frame, pixel, sample, branch, counter;
+    uint32_t cached_block = 0xffffffffu;
+    uint32_t o[4];
+};
 
 // uniform in [0,1] inclusive (rand()/RAND_MAX, Raytracer.cpp:65-67)
 RTX_DEV double rng_uniform(uint64_t seed, uint32_t frame, uint32_t pixel, uint32_t sample, uint32_t branch, uint32_t draw)
@@ -68,7 +73,18 @@ RTX_DEV double rng_uniform(uint64_t seed, uint32_t frame, uint32_t pixel, uint32
     uint32_t v = w == 0 ? o[0] : (w == 1 ? o[1] : (w == 2 ? o[2] : o[3]));
     return (double)v / 4294967295.0;
 }
-RTX_DEV double rng_next(Rng& r) { return rng_uniform(r.seed, r.frame, r.pixel, r.sample, r.branch, r.counter++); }
+RTX_DEV double rng_next(Rng& r)
+{
+    const uint32_t draw = r.counter++;
+    if ((draw >> 2) != r.cached_block) {
+        r.cached_block = draw >> 2;
+        philox4x32_10(r.pixel, r.sample, r.branch, draw >> 2, (uint32_t)r.seed,
+                      (uint32_t)(r.seed >> 32) ^ (r.frame * 0x9E3779B9u), r.o);
+    }
+    const uint32_t w = draw & 3u;
+    const uint32_t v = w == 0 ? r.o[0] : (w == 1 ? r.o[1] : (w == 2 ? r.o[2] : r.o[3]));
+    return (double)v / 4294967295.0;
+}
 
 // ---- Ray (Ray.cpp:3-8) --------------------------------------------------------------
 struct Ray { d3 o, d; };       // d normalised by make_ray; inverseDirection is -d
