@@ -73,6 +73,7 @@ struct Workspace {
     RayQueue q[2];
     ShadowQueue sq;
     uint32_t* shadow_index = nullptr;       // per ray: first shadow entry
+    uint32_t* shadow_stride = nullptr;      // per ray: distance between its entries
     uint32_t* perm = nullptr;               // shading order (material sort)
     uint32_t* bins = nullptr;               // 2 * kBins: histogram, next free place per bin
     double* sample = nullptr;               // 3 per slot
@@ -104,7 +105,7 @@ size_t queue_bytes(size_t cap)
 {
     auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
     size_t per_queue = 10 * al(cap * 8) + 4 * al(cap * 4) + al(cap * 4) + al(cap * 8);
-    return 2 * per_queue + 2 * al(cap * 4) + al(cap * 3 * 8);
+    return 2 * per_queue + 3 * al(cap * 4) + al(cap * 3 * 8);
 }
 
 }  // namespace
@@ -148,6 +149,7 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap)
             q.hit_prim = carve<int32_t>(p, cap); q.hit_depth = carve<double>(p, cap);
         }
         w.shadow_index = carve<uint32_t>(p, cap);
+        w.shadow_stride = carve<uint32_t>(p, cap);
         w.perm = carve<uint32_t>(p, cap);
         w.sample = carve<double>(p, cap * 3);
         w.capacity = cap;
@@ -724,7 +726,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 } else {
                     timer.begin();
                     hipLaunchKernelGGL(k_shade_whitted_a, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                       w.counts + 1, w.shadow_index, w.sample);
+                                       w.counts + 1, w.shadow_index, w.shadow_stride, w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                     // the shadow queue's length stays on the device: the launch is sized for the
@@ -741,7 +743,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                     }
                     timer.begin();
                     hipLaunchKernelGGL(k_shade_whitted_b, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                       w.shadow_index, nq, w.counts + 0, w.sample);
+                                       w.shadow_index, w.shadow_stride, nq, w.counts + 0, w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                 }

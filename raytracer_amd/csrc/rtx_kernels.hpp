@@ -635,8 +635,9 @@ RTX_DEV void pixel_of(const RenderParams& p, uint32_t t, uint32_t& x, uint32_t& 
 }
 
 // Block-wide reservation of queue space: one atomic per workgroup.  Every thread of the
-// workgroup must call it.  `lds` is kBlock/64 + 1 words of scratch.
-RTX_DEV uint32_t block_reserve(bool pred, uint32_t* counter, uint32_t per_item, uint32_t* lds)
+// workgroup must call it.  `lds` is kBlock/64 + 2 words of scratch.
+RTX_DEV uint32_t block_reserve(bool pred, uint32_t* counter, uint32_t per_item, uint32_t* lds, uint32_t* block_total = nullptr,
+                               uint32_t* block_base = nullptr, uint32_t* rank = nullptr)
 {
     unsigned long long mask = __ballot(pred);
     uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -648,8 +649,12 @@ RTX_DEV uint32_t block_reserve(bool pred, uint32_t* counter, uint32_t per_item, 
         uint32_t sum = 0;
         for (uint32_t k = 0; k < kBlock / 64; ++k) { uint32_t c = lds[k]; lds[k] = sum; sum += c; }
         lds[kBlock / 64] = sum ? atomicAdd(counter, sum * per_item) : 0u;
+        lds[kBlock / 64 + 1] = sum;
     }
     __syncthreads();
+    if (block_total) *block_total = lds[kBlock / 64 + 1];
+    if (block_base) *block_base = lds[kBlock / 64];
+    if (rank) *rank = lds[wave] + prefix;
     return lds[kBlock / 64] + (lds[wave] + prefix) * per_item;
 }
 
@@ -851,16 +856,16 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
             }
         }
     }
-    __shared__ uint32_t reserve_lds[kBlock / 64 + 1];
+    __shared__ uint32_t reserve_lds[kBlock / 64 + 2];
     uint32_t j = block_reserve(spawn, next_count, 1, reserve_lds);
     if (spawn && j < p.queue_cap) push_ray(next, j, child, cw, cior, slot, layer + 1, cbranch, ccounter);
 }
 
 // ---- rayTrace (Raytracer-Noah-Desktop.cpp:452-564), first half: emit the light rays -----------------
-// Hit rays get shadow_per_hit consecutive shadow-queue entries; shadow_base[i] records where.
+// Hit rays get shadow_per_hit shadow-queue entries, shadow_stride[i] apart from shadow_base[i] on.
 __global__ void __launch_bounds__(kBlock)
 k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, uint32_t* shadow_count,
-                  uint32_t* shadow_base, double* sample)
+                  uint32_t* shadow_base, uint32_t* shadow_stride, double* sample)
 {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool hit = false;
@@ -873,10 +878,14 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
         }
     }
     bool emit = hit && p.shadow_per_hit > 0 && !(p.d.flags & RTX_FLAG_NO_LIGHTING);
-    __shared__ uint32_t reserve_lds[kBlock / 64 + 1];
-    uint32_t base = block_reserve(emit, shadow_count, p.shadow_per_hit, reserve_lds);
-    if (i < n) shadow_base[i] = base;
-    if (emit && (unsigned long long)base + p.shadow_per_hit <= p.shadow_cap) {
+    __shared__ uint32_t reserve_lds[kBlock / 64 + 2];
+    // the workgroup's entries are laid out sample-major: entry (hit j of the workgroup, sample m)
+    // sits at block_base + m * block_hits + j, so that for one m the lanes write neighbours
+    uint32_t block_hits = 0, block_base = 0, rank = 0;
+    block_reserve(emit, shadow_count, p.shadow_per_hit, reserve_lds, &block_hits, &block_base, &rank);
+    const uint32_t base = block_base + rank;
+    if (i < n) { shadow_base[i] = base; shadow_stride[i] = block_hits; }
+    if (emit && (unsigned long long)block_base + (unsigned long long)block_hits * p.shadow_per_hit <= p.shadow_cap) {
         d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
         Hit h;
         prim_full(s, (uint32_t)q.hit_prim[i], o, d, h);
@@ -887,7 +896,7 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
         for (uint32_t li = 0; li < s.n_lights; ++li) {
             const rtx_light& l = s.lights[li];
             uint32_t samples = l.multisample ? p.d.light_multisample_n * p.d.light_multisample_n : 1u;
-            for (uint32_t sm = 0; sm < samples; ++sm, ++k) {
+            for (uint32_t sm = 0; sm < samples; ++sm, k += block_hits) {
                 double u0 = 0.0, u1 = 0.0;
                 if (l.kind == RTX_LIGHT_SQUARE) { u0 = rng_next(rng); u1 = rng_next(rng); }
                 Ray lr = light_ray(l, from, u0, u1);
@@ -903,7 +912,7 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
 // second half: direct lighting from the shadow results, blend, spawn children
 __global__ void __launch_bounds__(kBlock)
 k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, const uint32_t* shadow_base,
-                  RayQueue next, uint32_t* next_count, double* sample)
+                  const uint32_t* shadow_stride, RayQueue next, uint32_t* next_count, double* sample)
 {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool spawn_t = false, spawn_r = false;
@@ -925,10 +934,11 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
         } else {
             d3 direct = mk(0, 0, 0);
             uint32_t k = shadow_base[i];
+            const uint32_t stride = shadow_stride[i];
             for (uint32_t li = 0; li < s.n_lights; ++li) {
                 const rtx_light& l = s.lights[li];
                 uint32_t samples = l.multisample ? p.d.light_multisample_n * p.d.light_multisample_n : 1u;
-                for (uint32_t sm = 0; sm < samples; ++sm, ++k) {
+                for (uint32_t sm = 0; sm < samples; ++sm, k += stride) {
                     Ray lr;
                     lr.o = mk(sq.ox[k], sq.oy[k], sq.oz[k]);
                     lr.d = mk(sq.dx[k], sq.dy[k], sq.dz[k]);
@@ -969,7 +979,7 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
         }
         sample_add(sample, slot, w * (local * wl));
     }
-    __shared__ uint32_t reserve_lds[kBlock / 64 + 1];
+    __shared__ uint32_t reserve_lds[kBlock / 64 + 2];
     uint32_t jt = block_reserve(spawn_t, next_count, 1, reserve_lds);
     if (spawn_t && jt < p.queue_cap) push_ray(next, jt, child_t, wt, ni, slot, layer + 1, branch, counter);
     uint32_t jr = block_reserve(spawn_r, next_count, 1, reserve_lds);
