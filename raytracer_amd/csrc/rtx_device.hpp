@@ -195,9 +195,13 @@ struct Hit {
 
 // ---- Triangle::rayHit (Triangle.cpp:8-72) ---------------------------------------------
 // depth-only form used during traversal; returns false on a miss
+RTX_DEV bool triangle_depth(d3 a, d3 b, d3 c, d3 o, d3 d, double& depth);
 RTX_DEV bool triangle_depth(const double* __restrict__ p, d3 o, d3 d, double& depth)
 {
-    d3 a = ld3(p), b = ld3(p + 3), c = ld3(p + 6);
+    return triangle_depth(ld3(p), ld3(p + 3), ld3(p + 6), o, d, depth);
+}
+RTX_DEV bool triangle_depth(d3 a, d3 b, d3 c, d3 o, d3 d, double& depth)
+{
     d3 E1 = b - a, E2 = c - a;
     d3 pvec = cross(d, E2);
     double det = dot(E1, pvec);

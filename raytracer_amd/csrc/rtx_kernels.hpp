@@ -196,6 +196,31 @@ RTX_DEV void slab_finite(d3 bmin, d3 bmax, d3 o, d3 inv, double& tmin, double& t
     tmax = __builtin_fmin(__builtin_fmax(t0x, t1x), __builtin_fmin(__builtin_fmax(t0y, t1y), __builtin_fmax(t0z, t1z)));
 }
 
+// Slab test and distance cull of one BVH child box from shared differences.  `gap` is a lower
+// bound of how far the box is from the ray origin, to be compared with the caller's bound:
+// the squared Euclidean distance (closest-hit form), or, cheaper, the largest per-axis gap
+// (LINF form: never above the Euclidean distance, so culling with it is as safe).
+template <bool LINF>
+RTX_DEV void slab_and_gap(d3 bmin, d3 bmax, d3 o, d3 inv, double& tmin, double& tmax, double& gap)
+{
+    const double ax = bmin.x - o.x, bx = bmax.x - o.x;
+    const double ay = bmin.y - o.y, by = bmax.y - o.y;
+    const double az = bmin.z - o.z, bz = bmax.z - o.z;
+    const double t0x = ax * inv.x, t1x = bx * inv.x;
+    const double t0y = ay * inv.y, t1y = by * inv.y;
+    const double t0z = az * inv.z, t1z = bz * inv.z;
+    tmin = __builtin_fmax(__builtin_fmin(t0x, t1x), __builtin_fmax(__builtin_fmin(t0y, t1y), __builtin_fmin(t0z, t1z)));
+    tmax = __builtin_fmin(__builtin_fmax(t0x, t1x), __builtin_fmin(__builtin_fmax(t0y, t1y), __builtin_fmax(t0z, t1z)));
+    // o - bmax == -(bmax - o) exactly
+    const double gx = __builtin_fmax(ax, -bx), gy = __builtin_fmax(ay, -by), gz = __builtin_fmax(az, -bz);
+    if constexpr (LINF) {
+        gap = __builtin_fmax(gx, __builtin_fmax(gy, gz));
+    } else {
+        const double ex = __builtin_fmax(gx, 0.0), ey = __builtin_fmax(gy, 0.0), ez = __builtin_fmax(gz, 0.0);
+        gap = (ex * ex + ey * ey) + ez * ez;
+    }
+}
+
 RTX_DEV double box_distance2(d3 bmin, d3 bmax, d3 o)
 {
     double ex = __builtin_fmax(__builtin_fmax(bmin.x - o.x, o.x - bmax.x), 0.0);
@@ -443,8 +468,10 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     bool tie = false;
     d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     const double abs_margin = 1e-9 * (s.scene_scale + __builtin_fmax(fabs(o.x), __builtin_fmax(fabs(o.y), fabs(o.z))));
+    // closest hit: squared distance bound; any hit: the light distance itself, compared with
+    // the largest per-axis gap
     double bound2 = kInf;
-    if constexpr (ANYHIT) { double bd = limit * (1.0 + 1e-7) + abs_margin; bound2 = bd * bd; }
+    if constexpr (ANYHIT) bound2 = limit * (1.0 + 1e-7) + abs_margin;
     int sp = 0;
     int32_t node = s.bvh_root;
     bool done = false;
@@ -455,12 +482,12 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
             const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
             const d3 lb0 = mk(n0.x, n0.y, n0.z), lb1 = mk(n0.w, n1.x, n1.y);
             const d3 rb0 = mk(n1.z, n1.w, n2.x), rb1 = mk(n2.y, n2.z, n2.w);
-            double lmin, lmax, rmin, rmax;
-            slab_finite(lb0, lb1, o, inv, lmin, lmax);
-            slab_finite(rb0, rb1, o, inv, rmin, rmax);
+            double lmin, lmax, rmin, rmax, lgap, rgap;
+            slab_and_gap<ANYHIT>(lb0, lb1, o, inv, lmin, lmax, lgap);
+            slab_and_gap<ANYHIT>(rb0, rb1, o, inv, rmin, rmax, rgap);
             if constexpr (COUNT) w.content += 2;
-            bool hl = lmin <= lmax && lmax >= 0.0 && !(box_distance2(lb0, lb1, o) > bound2);
-            bool hr = rmin <= rmax && rmax >= 0.0 && !(box_distance2(rb0, rb1, o) > bound2);
+            bool hl = lmin <= lmax && lmax >= 0.0 && !(lgap > bound2);
+            bool hr = rmin <= rmax && rmax >= 0.0 && !(rgap > bound2);
             int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
             if (hl && hr) {
                 bool left_first = lmin <= rmin;
@@ -478,6 +505,9 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
             for (uint32_t k = 0; k < count; ++k, ++q) {
                 // Shape::rayAABB && rayHit (KDTree.cpp:208-211) commute: rayHit first, and the
                 // shape's box is only fetched for a hit that could change the result
+                // the whole record in one go: ids and positions arrive together instead of the
+                // positions waiting for the type to be known
+                const d3 ta = ld3(q->p), tb = ld3(q->p + 3), tc = ld3(q->p + 6);
                 uint32_t shape = q->shape, info = q->info;
                 uint32_t type = info & 3u, idx = info >> 2;
                 double depth = kInf;
@@ -485,7 +515,7 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 bool ok;
                 if (type == RTX_PRIM_TRIANGLE) {
                     if constexpr (COUNT) w.tri++;
-                    ok = triangle_depth(q->p, o, d, depth);
+                    ok = triangle_depth(ta, tb, tc, o, d, depth);
                 } else if (type == RTX_PRIM_SPHERE) {
                     if constexpr (COUNT) w.sph++;
                     ok = sphere_t(ld3(s.sph_center + 3 * (size_t)idx), s.sph_r2[idx], o, d, depth);
