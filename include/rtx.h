@@ -199,9 +199,13 @@ enum {
                                            walk instead of the reference-order one; the
                                            leaf outputs and counters then describe that
                                            walk's own work, not the reference's            */
-    RTX_FLAG_SORT_MATERIAL   = 1u << 9  /* pathTrace levels are shaded in material order
+    RTX_FLAG_SORT_MATERIAL   = 1u << 9, /* pathTrace levels are shaded in material order
                                            (rays binned by the material they hit) instead
                                            of queue order; same image                      */
+    RTX_FLAG_GLOBAL_LIGHTING = 1u << 10 /* Whitted with GLOBAL_LIGHTING: the hemisphere gather
+                                           inside the light loop
+                                           (Raytracer-Noah-Desktop.cpp:69,499-524), with
+                                           rtx_render_desc.global_samples = MONTE_CARLO_SAMPLES */
 };
 
 /* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;
@@ -224,6 +228,11 @@ typedef struct rtx_render_desc {
     double clear_color[3];
     double attenuation[3];          /* LIGHT_CONTSTANT, LIGHT_LINEAR, LIGHT_QUADRATIC   */
     rtx_camera camera;
+    uint32_t global_samples;        /* MONTE_CARLO_SAMPLES of the Whitted variant
+                                       (Raytracer-Noah-Desktop.cpp:73): gather rays per light
+                                       and hit at layer 0, divided by layer+1 below (:500);
+                                       read only with RTX_FLAG_GLOBAL_LIGHTING             */
+    uint32_t reserved;              /* 0 */
 } rtx_render_desc;
 
 typedef struct rtx_stats {

@@ -535,12 +535,11 @@ static v3 refraction_ray(v3 n, v3 d, double ior, int entering, int* internal_onl
     return normalize3(best);
 }
 
-/* -rotate(d, pi, n), Raytracer.cpp:284: glm::rotate(v, angle, normal) of
- * gtx/rotate_vector = mat3(rotate(mat4(1), angle, normal)) * v */
-static v3 mirror_direction(v3 d, v3 n)
+/* glm::rotate(v, angle, normal) of gtx/rotate_vector = mat3(rotate(mat4(1), angle, normal)) * v,
+ * with c = cos(angle), s = sin(angle) supplied by the caller */
+static v3 rotate_vec(v3 v, double c, double s, v3 normal)
 {
-    const double c = cos(PI), s = sin(PI);
-    v3 axis = normalize3(n);
+    v3 axis = normalize3(normal);
     v3 temp = muls(axis, 1.0 - c);
     double R[3][3];
     R[0][0] = c + temp.x * axis.x;
@@ -562,10 +561,16 @@ static v3 mirror_direction(v3 d, v3 n)
             M[i][k] = (e0 + e1) + e2;
         }
     v3 o;
-    o.x = M[0][0] * d.x + M[1][0] * d.y + M[2][0] * d.z;
-    o.y = M[0][1] * d.x + M[1][1] * d.y + M[2][1] * d.z;
-    o.z = M[0][2] * d.x + M[1][2] * d.y + M[2][2] * d.z;
-    return neg(o);
+    o.x = M[0][0] * v.x + M[1][0] * v.y + M[2][0] * v.z;
+    o.y = M[0][1] * v.x + M[1][1] * v.y + M[2][1] * v.z;
+    o.z = M[0][2] * v.x + M[1][2] * v.y + M[2][2] * v.z;
+    return o;
+}
+
+/* -rotate(d, pi, n), Raytracer.cpp:284 */
+static v3 mirror_direction(v3 d, v3 n)
+{
+    return neg(rotate_vec(d, cos(PI), sin(PI), n));
 }
 
 /* Xchi / Gp / G, CookTorrance.cpp:11-15,56-76 */
@@ -609,6 +614,23 @@ static v3 random_hemispherical(v3 normal, rng_t* rng)
         out = normalize3(V(a, b, c));
     } while (dot(normal, out) < 0.0);
     return out;
+}
+
+/* randomHemisphericalVector of the Whitted variant, Raytracer-Noah-Desktop.cpp:149-166:
+ * two uniforms (theta first, then phi); b1/b2 are computed there and never used.  The
+ * vector is NOT confined to the hemisphere, and for a normal parallel to worldUp the
+ * rotation axis is the zero vector, whose normalisation makes every component NaN --
+ * both kept as they are. */
+static v3 random_hemispherical_desktop(v3 normal, rng_t* rng)
+{
+    normal = normalize3(normal);
+    v3 world_up = normal.y > 0.9 ? V(0.0, 1.0, 0.0) : V(1.0, 0.0, 0.0);
+    double theta = (2.0 * PI) * rng_next(rng);
+    double phi = acos(1.0 - (2.0 * rng_next(rng)));
+    v3 nv = V(sin(theta) * sin(phi), sin(theta) * cos(phi), sin(phi));
+    v3 rot_vector = cross(normal, world_up);
+    double rot_rads = acos(dot(normal, world_up));
+    return rotate_vec(nv, cos(rot_rads), sin(rot_rads), rot_vector);
 }
 
 /* ---------------------------------------------------------- integrators --- */
@@ -688,14 +710,36 @@ static v3 path_trace(render_ctx* rc, const ray_t* ray, rng_t* rng, double curren
     return radiance;
 }
 
-/* rayTrace, Raytracer-Noah-Desktop.cpp:452-564, LIGHTING on, GLOBAL_LIGHTING
- * off.  RTX_FLAG_WHITTED_REFLECT adds a mirror ray that the reference does
+/* globalSamples of Raytracer-Noah-Desktop.cpp:500:
+ *   int(MONTE_CARLO_SAMPLES * ((double(MAXBOUNCES)/double(layer+1))/double(MAXBOUNCES)))
+ * MAXBOUNCES = 0 makes the factor NaN, whose conversion is undefined: no samples then. */
+static int global_samples_at(const rtx_render_desc* d, uint32_t layer)
+{
+    if (d->max_depth == 0) return 0;
+    double f = ((double)d->max_depth / (double)(layer + 1)) / (double)d->max_depth;
+    return (int)((double)d->global_samples * f);
+}
+
+/* The gather's nested rayTrace call (Desktop :510) feeds only two things back: whether it
+ * hit, and where (its colour lands in a shadowing local, :509).  With this switch off the
+ * oracle evaluates just those -- one shootRay when layer+1 <= MAXBOUNCES; with it on it runs
+ * the whole nested call as the reference does, on a random stream of its own, and throws
+ * the colour away.  Both give the same image (tests/test_oracle_kat.py); the nested work
+ * grows as the product of the per-layer sample counts. */
+static int g_global_full_recursion = 0;
+void orc_set_global_full_recursion(int on) { g_global_full_recursion = on; }
+
+/* rayTrace, Raytracer-Noah-Desktop.cpp:452-564, LIGHTING on; GLOBAL_LIGHTING
+ * (:499-524) with RTX_FLAG_GLOBAL_LIGHTING.  RTX_FLAG_WHITTED_REFLECT adds a
+ * mirror ray that the reference does
  * not have (its rayTrace only recurses for refraction):
  *   local = (1-smooth)*local + smooth*rayTrace(mirror ray), smooth != 0,
  * with the mirror ray of pathTrace case 2 (Raytracer.cpp:284-285).  The mirror
  * child draws from its own random stream (branch | 1<<layer, counter 0) so the
- * result does not depend on evaluation order. */
-static int ray_trace(render_ctx* rc, const ray_t* ray, rng_t* rng, v3* color, double current_ior, uint32_t layer)
+ * result does not depend on evaluation order.  `hit_out`, when not NULL, receives
+ * minRayResult (untouched when the layer limit ends the call before shootRay). */
+static int ray_trace(render_ctx* rc, const ray_t* ray, rng_t* rng, v3* color, double current_ior, uint32_t layer,
+                     hit_t* hit_out)
 {
     const rtx_scene_desc* s = rc->s;
     const rtx_render_desc* d = rc->d;
@@ -705,10 +749,12 @@ static int ray_trace(render_ctx* rc, const ray_t* ray, rng_t* rng, v3* color, do
     *color = V(0, 0, 0);
     count_ray(rc, layer);
     hit_t h = shoot_ray(s, ray, d->flags, &rc->ctx);
+    if (hit_out) *hit_out = h;
     if (h.prim < 0) { *color = clear; return 0; }
     const rtx_material* m = &s->materials[s->prim_material[h.prim]];
     int entering = is_entering(h.normal, ray);
     v3 direct = V(0, 0, 0);
+    v3 global = V(0, 0, 0);
     if (!(d->flags & RTX_FLAG_NO_LIGHTING)) {
         for (uint32_t li = 0; li < s->n_lights; ++li) {
             const rtx_light* l = &s->lights[li];
@@ -726,6 +772,37 @@ static int ray_trace(render_ctx* rc, const ray_t* ray, rng_t* rng, v3* color, do
                 }
             }
             direct = divs(direct, (double)samples);    /* inside the light loop, :498 */
+            if (d->flags & RTX_FLAG_GLOBAL_LIGHTING) {  /* :499-524, inside the light loop as well */
+                int gs = global_samples_at(d, layer);
+                for (int i = 0; i < gs; ++i) {
+                    v3 origin = h.position;             /* no bias here */
+                    ray_t lray = make_ray(origin, random_hemispherical_desktop(h.normal, rng));
+                    hit_t lh;
+                    memset(&lh, 0, sizeof lh);
+                    int lhit;
+                    if (g_global_full_recursion) {
+                        rng_t fork = *rng;
+                        fork.branch = (rng->branch * 0x9E3779B1u) ^ ((layer + 1u) << 24) ^ (li << 16) ^ (uint32_t)i ^ 0x80000000u;
+                        fork.counter = 0;
+                        v3 unused;
+                        lhit = ray_trace(rc, &lray, &fork, &unused, material_ni(s, m, h.u, h.v), layer + 1, &lh);
+                    } else if (layer + 1 > d->max_depth) {
+                        lhit = 0;                       /* the nested call returns before shootRay, :456-460 */
+                    } else {
+                        count_ray(rc, layer + 1);
+                        lh = shoot_ray(s, &lray, d->flags, &rc->ctx);
+                        lhit = lh.prim >= 0;
+                    }
+                    if (lhit) {
+                        double ray_distance = distance3(origin, lh.position);
+                        double att = light_attenuation(l, ray_distance, d->attenuation);
+                        global = add(global, lighting(s, ray, &lray, h.normal, h.u, h.v, att, m, ld3(l->color)));
+                    } else {
+                        global = add(global, muls(clear, 0.04));
+                    }
+                }
+                global = divs(global, (double)d->global_samples);   /* :523 */
+            }
         }
     }
     v3 transparent = clear;
@@ -736,11 +813,11 @@ static int ray_trace(render_ctx* rc, const ray_t* ray, rng_t* rng, v3* color, do
         v3 dir = refraction_ray(normalize3(h.normal), normalize3(ray->direction), ni, entering, &internal_only);
         v3 pos = add(h.position, muls(muls(h.normal, entering ? -1.0 : 1.0), d->bias));
         ray_t child = make_ray(pos, dir);
-        ray_trace(rc, &child, rng, &transparent, ni, layer + 1);
+        ray_trace(rc, &child, rng, &transparent, ni, layer + 1, NULL);
     }
     v3 local;
     if (d->flags & RTX_FLAG_NO_LIGHTING) local = material_color(s, m, h.u, h.v);
-    else local = direct;
+    else local = add(direct, global);                   /* :553 */
     if (d->flags & RTX_FLAG_WHITTED_REFLECT) {
         double smooth = material_smoothness(s, m, h.u, h.v);
         if (smooth != 0.0) {
@@ -750,7 +827,7 @@ static int ray_trace(render_ctx* rc, const ray_t* ray, rng_t* rng, v3* color, do
             fork.branch = rng->branch | (1u << (layer & 31u));
             fork.counter = 0;
             v3 reflected;
-            ray_trace(rc, &child, &fork, &reflected, ni, layer + 1);
+            ray_trace(rc, &child, &fork, &reflected, ni, layer + 1, NULL);
             local = add(muls(local, 1.0 - smooth), muls(reflected, smooth));
         }
     }
@@ -816,7 +893,7 @@ int orc_render(const rtx_scene_desc* s, const rtx_render_desc* d, float* accum, 
                                       pass * n * n + (sx - 1) * n + (sy - 1), 0, 0 };
                         v3 c;
                         if (d->integrator == RTX_INTEGRATOR_PATH) c = path_trace(&rc, &ray, &rng, 1.0, 0);
-                        else ray_trace(&rc, &ray, &rng, &c, 1.0, 0);
+                        else ray_trace(&rc, &ray, &rng, &c, 1.0, 0, NULL);
                         acum = add(acum, c);
                     }
                 v3 px = divs(acum, (double)(n * n));

@@ -37,6 +37,11 @@ int orc_trace_closest(const rtx_scene_desc* s, const double* origin, const doubl
 int orc_render(const rtx_scene_desc* s, const rtx_render_desc* d, float* accum, double* rgb64,
                rtx_stats* stats, int threads, int* threads_used);
 
+/* GLOBAL_LIGHTING gather (Raytracer-Noah-Desktop.cpp:499-524): on != 0 makes orc_render run
+ * the gather's nested rayTrace calls in full, as the reference does, although only their
+ * hit/position can reach the image; the default evaluates just the hit.  Process-wide. */
+void orc_set_global_full_recursion(int on);
+
 /* camera ray of one sub-sample: Raytracer.cpp:676-700 */
 void orc_camera_ray(const rtx_render_desc* d, uint32_t px, uint32_t py, uint32_t sx, uint32_t sy,
                     double origin[3], double direction[3]);

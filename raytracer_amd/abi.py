@@ -35,6 +35,7 @@ FLAG_KD_CULLED = 1 << 6
 FLAG_STAGE_TIMES = 1 << 7
 FLAG_RENDER_WALK = 1 << 8
 FLAG_SORT_MATERIAL = 1 << 9
+FLAG_GLOBAL_LIGHTING = 1 << 10
 
 TONEMAP_NONE, TONEMAP_CBRT = 0, 1
 
@@ -115,6 +116,7 @@ class RenderDesc(C.Structure):
         ("frame", C.c_uint32), ("seed", C.c_uint64),
         ("bias", C.c_double), ("clear_color", D3), ("attenuation", D3),
         ("camera", Camera),
+        ("global_samples", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 

@@ -68,23 +68,28 @@ struct DeviceBuffers {
 struct Workspace {
     size_t capacity = 0;            // rays per queue
     size_t shadow_capacity = 0;
+    size_t gather_capacity = 0;
     char* base = nullptr;
     char* shadow_base_mem = nullptr;
+    char* gather_base_mem = nullptr;
     RayQueue q[2];
     ShadowQueue sq;
+    GatherQueue gq;
+    uint32_t* gather_index = nullptr;       // per ray: first gather entry
     uint32_t* shadow_index = nullptr;       // per ray: first shadow entry
     uint32_t* shadow_stride = nullptr;      // per ray: distance between its entries
     uint32_t* perm = nullptr;               // shading order (material sort)
     uint32_t* bins = nullptr;               // 2 * kBins: histogram, next free place per bin
     double* sample = nullptr;               // 3 per slot
-    uint32_t* counts = nullptr;             // [0] next queue, [1] shadow queue, [2] generate
-    unsigned long long* work = nullptr;     // 8 work counters + the shadow rays of single-level frames
+    uint32_t* counts = nullptr;             // [0] next queue, [1] shadow queue, [2] gather queue
+    unsigned long long* work = nullptr;     // 8 work counters + the shadow and gather rays of single-level frames
     uint32_t* host_counts = nullptr;        // pinned
     unsigned long long* host_work = nullptr;
     ~Workspace()
     {
         if (base) (void)hipFree(base);
         if (shadow_base_mem) (void)hipFree(shadow_base_mem);
+        if (gather_base_mem) (void)hipFree(gather_base_mem);
         if (counts) (void)hipFree(counts);
         if (bins) (void)hipFree(bins);
         if (work) (void)hipFree(work);
@@ -105,7 +110,7 @@ size_t queue_bytes(size_t cap)
 {
     auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
     size_t per_queue = 10 * al(cap * 8) + 4 * al(cap * 4) + al(cap * 4) + al(cap * 8);
-    return 2 * per_queue + 3 * al(cap * 4) + al(cap * 3 * 8);
+    return 2 * per_queue + 4 * al(cap * 4) + al(cap * 3 * 8);
 }
 
 }  // namespace
@@ -123,16 +128,16 @@ struct rtx_scene {
 
 namespace {
 
-int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap)
+int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap, size_t gather_cap)
 {
     Workspace& w = sc->ws;
     if (!w.counts) {
         HIP_TRY(hipMalloc(&w.counts, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&w.work, 9 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&w.work, 10 * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc(&w.bins, 2 * kBins * sizeof(uint32_t)));
         HIP_TRY(hipMemset(w.bins, 0, 2 * kBins * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc(&w.host_counts, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc(&w.host_work, 9 * sizeof(unsigned long long)));
+        HIP_TRY(hipHostMalloc(&w.host_work, 10 * sizeof(unsigned long long)));
     }
     if (cap > w.capacity) {
         if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.capacity = 0; }
@@ -150,6 +155,7 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap)
         }
         w.shadow_index = carve<uint32_t>(p, cap);
         w.shadow_stride = carve<uint32_t>(p, cap);
+        w.gather_index = carve<uint32_t>(p, cap);
         w.perm = carve<uint32_t>(p, cap);
         w.sample = carve<double>(p, cap * 3);
         w.capacity = cap;
@@ -165,6 +171,18 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap)
         s.limit = carve<double>(p, shadow_cap);
         s.hit_depth = carve<double>(p, shadow_cap);
         w.shadow_capacity = shadow_cap;
+    }
+    if (gather_cap > w.gather_capacity) {
+        if (w.gather_base_mem) { HIP_TRY(hipFree(w.gather_base_mem)); w.gather_base_mem = nullptr; w.gather_capacity = 0; }
+        auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
+        HIP_TRY(hipMalloc(&w.gather_base_mem, 7 * al(gather_cap * 8) + al(gather_cap * 4)));
+        char* p = w.gather_base_mem;
+        GatherQueue& g = w.gq;
+        g.ox = carve<double>(p, gather_cap); g.oy = carve<double>(p, gather_cap); g.oz = carve<double>(p, gather_cap);
+        g.dx = carve<double>(p, gather_cap); g.dy = carve<double>(p, gather_cap); g.dz = carve<double>(p, gather_cap);
+        g.hit_depth = carve<double>(p, gather_cap);
+        g.hit_prim = carve<int32_t>(p, gather_cap);
+        w.gather_capacity = gather_cap;
     }
     return RTX_OK;
 }
@@ -652,11 +670,28 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
             shadow_per_hit += l.multisample ? rd->light_multisample_n * rd->light_multisample_n : 1u;
     }
     p.shadow_per_hit = shadow_per_hit;
+    // GLOBAL_LIGHTING: globalSamples per light at a level (Raytracer-Noah-Desktop.cpp:500); MAXBOUNCES = 0
+    // makes the reference's factor NaN, taken as no samples
+    const bool gather = whitted && (rd->flags & RTX_FLAG_GLOBAL_LIGHTING) && !(rd->flags & RTX_FLAG_NO_LIGHTING) &&
+                        rd->global_samples > 0 && rd->max_depth > 0 && sc->d.n_lights > 0;
+    auto gather_samples_at = [&](uint32_t layer) -> uint32_t {
+        if (!gather) return 0u;
+        double f = ((double)rd->max_depth / (double)(layer + 1)) / (double)rd->max_depth;
+        return (uint32_t)(int)((double)rd->global_samples * f);
+    };
+    const uint64_t gather_per_hit0 = (uint64_t)gather_samples_at(0) * sc->d.n_lights;   // the most any level emits
 
     // chunk size: whole 8x8 pixel blocks, bounded by the path budget
     size_t max_paths = 8u << 20;
     if (const char* env = std::getenv("RTX_MAX_PATHS")) { long v = std::atol(env); if (v >= 64) max_paths = (size_t)v; }
     uint64_t pixels_per_chunk = std::max<uint64_t>(64, (max_paths / nn) / 64 * 64);
+    if (gather_per_hit0) {
+        // bound the gather queue (60 bytes per entry) to a few GB
+        size_t max_gather = 64u << 20;
+        if (const char* env = std::getenv("RTX_MAX_GATHER")) { long v = std::atol(env); if (v >= 64) max_gather = (size_t)v; }
+        uint64_t by_gather = std::max<uint64_t>(64, (max_gather / (gather_per_hit0 * nn)) / 64 * 64);
+        pixels_per_chunk = std::min(pixels_per_chunk, by_gather);
+    }
     pixels_per_chunk = std::min<uint64_t>(pixels_per_chunk, padded_pixels);
     // the mirror extension can double the queue at every level
     size_t fan = (whitted && (rd->flags & RTX_FLAG_WHITTED_REFLECT)) ? 2 : 1;
@@ -667,12 +702,16 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         for (uint32_t l = 0; l < std::min<uint32_t>(rd->max_depth, 4); ++l) growth *= 2;
         queue_cap = cap * growth;
     }
-    int rc = ensure_workspace(sc, queue_cap, whitted ? queue_cap * std::max<uint32_t>(shadow_per_hit, 1) : 0);
+    if (queue_cap * std::max<uint64_t>(gather_per_hit0, 1) > 0xffffffffull || queue_cap * (uint64_t)std::max<uint32_t>(shadow_per_hit, 1) > 0xffffffffull)
+        return fail(RTX_ERR_LIMIT, "shadow / gather queue of one chunk exceeds 2^32 entries: lower RTX_MAX_PATHS");
+    int rc = ensure_workspace(sc, queue_cap, whitted ? queue_cap * std::max<uint32_t>(shadow_per_hit, 1) : 0,
+                              (size_t)(queue_cap * gather_per_hit0));
     if (rc != RTX_OK) return rc;
     Workspace& w = sc->ws;
     hipStream_t st = sc->stream;
     p.queue_cap = (uint32_t)std::min<size_t>(w.capacity, 0xffffffffu);
     p.shadow_cap = (uint32_t)std::min<size_t>(w.shadow_capacity, 0xffffffffu);
+    p.gather_cap = (uint32_t)std::min<size_t>(w.gather_capacity, 0xffffffffu);
 
     rtx_stats local;
     std::memset(&local, 0, sizeof local);
@@ -681,7 +720,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, st)); }
     if (count_work) HIP_TRY(hipMemsetAsync(w.work, 0, 8 * sizeof(unsigned long long), st));
     const bool single_level = whitted && !sc->may_refract && !(rd->flags & RTX_FLAG_WHITTED_REFLECT);
-    if (single_level) HIP_TRY(hipMemsetAsync(w.work + 8, 0, sizeof(unsigned long long), st));
+    if (single_level) HIP_TRY(hipMemsetAsync(w.work + 8, 0, 2 * sizeof(unsigned long long), st));
 
     for (uint32_t pass = rd->first_pass; pass < rd->first_pass + rd->passes; ++pass) {
         p.pass = pass;
@@ -710,7 +749,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 if (rc != RTX_OK) return rc;
                 timer.end(&local.ms_traverse);
                 local.traverse_launches++;
-                HIP_TRY(hipMemsetAsync(w.counts, 0, 2 * sizeof(uint32_t), st));
+                HIP_TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), st));
                 if (!whitted) {
                     timer.begin();
                     const uint32_t* perm = nullptr;
@@ -724,9 +763,14 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                 } else {
+                    p.gather_samples = gather_samples_at(level);
+                    p.gather_traced = level + 1 <= rd->max_depth ? 1u : 0u;
+                    const uint64_t gather_max = p.gather_traced ? (uint64_t)count * p.gather_samples * sc->d.n_lights : 0;
+                    if (gather_max > w.gather_capacity) return fail(RTX_ERR_LIMIT, "gather queue overflow");
                     timer.begin();
                     hipLaunchKernelGGL(k_shade_whitted_a, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                       w.counts + 1, w.shadow_index, w.shadow_stride, w.sample);
+                                       w.counts + 1, w.shadow_index, w.shadow_stride, w.gq, w.counts + 2, w.gather_index,
+                                       w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                     // the shadow queue's length stays on the device: the launch is sized for the
@@ -741,9 +785,19 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                         timer.end(&local.ms_shadow);
                         local.traverse_launches++;
                     }
+                    if (gather_max > 0) {
+                        // the gather's nested rayTrace calls, reduced to what reaches the image: one
+                        // closest-hit query each (their colour is discarded, :509-510)
+                        timer.begin();
+                        rc = launch_trace(sc, w.gq.ox, w.gq.oy, w.gq.oz, w.gq.dx, w.gq.dy, w.gq.dz, nullptr, (uint32_t)gather_max,
+                                          w.counts + 2, rd->flags, w.gq.hit_prim, w.gq.hit_depth, count_work);
+                        if (rc != RTX_OK) return rc;
+                        timer.end(&local.ms_traverse);
+                        local.traverse_launches++;
+                    }
                     timer.begin();
                     hipLaunchKernelGGL(k_shade_whitted_b, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                       w.shadow_index, w.shadow_stride, nq, w.counts + 0, w.sample);
+                                       w.shadow_index, w.shadow_stride, w.gq, w.gather_index, nq, w.counts + 0, w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                 }
@@ -752,14 +806,16 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                     // off: this level is the last one and the host need not wait to learn that.
                     // The shadow-ray count is summed on the device and read with the frame's end.
                     hipLaunchKernelGGL(k_add_count, dim3(1), dim3(1), 0, st, w.counts + 1, w.work + 8);
+                    hipLaunchKernelGGL(k_add_count, dim3(1), dim3(1), 0, st, w.counts + 2, w.work + 9);
                     HIP_TRY(hipGetLastError());
                     break;
                 }
                 // one readback per level: next queue length and (Whitted) shadow rays traced
-                HIP_TRY(hipMemcpyAsync(w.host_counts, w.counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(w.host_counts, w.counts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 count = w.host_counts[0];
                 local.rays_shadow += w.host_counts[1];
+                local.rays_secondary += w.host_counts[2];      // gather rays are layer+1 shootRay calls
                 cur ^= 1;
                 ++level;
             }
@@ -772,10 +828,10 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     if (count_work) {
         HIP_TRY(hipMemcpyAsync(w.host_work, w.work, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     }
-    if (single_level) HIP_TRY(hipMemcpyAsync(w.host_work + 8, w.work + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (single_level) HIP_TRY(hipMemcpyAsync(w.host_work + 8, w.work + 8, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (stats) HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (single_level) local.rays_shadow += w.host_work[8];
+    if (single_level) { local.rays_shadow += w.host_work[8]; local.rays_secondary += w.host_work[9]; }
     if (stats) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));

@@ -439,11 +439,11 @@ RTX_DEV d3 refraction_ray(d3 n, d3 d, double ior, bool entering)
     return normalize3(best);
 }
 
-// -rotate(d, pi, n) (Raytracer.cpp:284)
-RTX_DEV d3 mirror_direction(d3 d, d3 n)
+// glm::rotate(v, angle, normal) of gtx/rotate_vector = mat3(rotate(mat4(1), angle, normal)) * v,
+// with c = cos(angle), s = sin(angle) supplied by the caller
+RTX_DEV d3 rotate_vec(d3 v, double c, double s, d3 normal)
 {
-    const double c = kCosPi, s = kSinPi;
-    d3 axis = normalize3(n);
+    d3 axis = normalize3(normal);
     d3 temp = axis * (1.0 - c);
     double R[3][3];
     R[0][0] = c + temp.x * axis.x;
@@ -466,10 +466,28 @@ RTX_DEV d3 mirror_direction(d3 d, d3 n)
             M[i][k] = (e0 + e1) + e2;
         }
     d3 o;
-    o.x = M[0][0] * d.x + M[1][0] * d.y + M[2][0] * d.z;
-    o.y = M[0][1] * d.x + M[1][1] * d.y + M[2][1] * d.z;
-    o.z = M[0][2] * d.x + M[1][2] * d.y + M[2][2] * d.z;
-    return -o;
+    o.x = M[0][0] * v.x + M[1][0] * v.y + M[2][0] * v.z;
+    o.y = M[0][1] * v.x + M[1][1] * v.y + M[2][1] * v.z;
+    o.z = M[0][2] * v.x + M[1][2] * v.y + M[2][2] * v.z;
+    return o;
+}
+
+// -rotate(d, pi, n) (Raytracer.cpp:284)
+RTX_DEV d3 mirror_direction(d3 d, d3 n) { return -rotate_vec(d, kCosPi, kSinPi, n); }
+
+// randomHemisphericalVector of the Whitted variant (Raytracer-Noah-Desktop.cpp:149-166):
+// two uniforms, theta first; not confined to the hemisphere; NaN for a normal parallel to
+// worldUp (the rotation axis is then the zero vector) -- both as in the reference
+RTX_DEV d3 random_hemispherical_desktop(d3 normal, Rng& rng)
+{
+    normal = normalize3(normal);
+    d3 world_up = normal.y > 0.9 ? mk(0.0, 1.0, 0.0) : mk(1.0, 0.0, 0.0);
+    double theta = (2.0 * kPi) * rng_next(rng);
+    double phi = acos(1.0 - (2.0 * rng_next(rng)));
+    d3 nv = mk(sin(theta) * sin(phi), sin(theta) * cos(phi), sin(phi));
+    d3 rot_vector = cross(normal, world_up);
+    double rot_rads = acos(dot(normal, world_up));
+    return rotate_vec(nv, cos(rot_rads), sin(rot_rads), rot_vector);
 }
 
 // Xchi / Gp (CookTorrance.cpp:11-15,56-72)

@@ -39,6 +39,14 @@ struct ShadowQueue {
     double *hit_depth;
 };
 
+// the gather rays of GLOBAL_LIGHTING (Raytracer-Noah-Desktop.cpp:499-524): closest-hit queries
+// whose hit (or miss) and distance are all that is used
+struct GatherQueue {
+    double *ox, *oy, *oz, *dx, *dy, *dz;
+    int32_t *hit_prim;
+    double *hit_depth;
+};
+
 struct Counters { unsigned long long* c; };     // 8 global work counters, or null
 
 struct RenderParams {
@@ -50,6 +58,10 @@ struct RenderParams {
     uint32_t shadow_per_hit;    // sum over lights of samples
     uint32_t queue_cap;         // entries a ray queue can hold; writes beyond are dropped and
     uint32_t shadow_cap;        //   the host turns the overshooting count into RTX_ERR_LIMIT
+    // GLOBAL_LIGHTING at the level being shaded (all rays of a level share their layer):
+    uint32_t gather_samples;    // globalSamples per light (:500); 0 = off
+    uint32_t gather_traced;     // 1 when layer+1 <= MAXBOUNCES, i.e. the nested call shoots its ray
+    uint32_t gather_cap;
 };
 
 // ---- traversal core -------------------------------------------------------------------------
@@ -892,10 +904,14 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
 }
 
 // ---- rayTrace (Raytracer-Noah-Desktop.cpp:452-564), first half: emit the light rays -----------------
-// Hit rays get shadow_per_hit shadow-queue entries, shadow_stride[i] apart from shadow_base[i] on.
+// Hit rays get shadow_per_hit shadow-queue entries, shadow_stride[i] apart from shadow_base[i] on,
+// and with GLOBAL_LIGHTING n_lights * gather_samples gather-queue entries, the same stride apart
+// from gather_base[i] on.  Random numbers are drawn in the reference's order: per light first
+// the SquareLight samples, then the gather directions.
 __global__ void __launch_bounds__(kBlock)
 k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, uint32_t* shadow_count,
-                  uint32_t* shadow_base, uint32_t* shadow_stride, double* sample)
+                  uint32_t* shadow_base, uint32_t* shadow_stride, GatherQueue gq, uint32_t* gather_count,
+                  uint32_t* gather_base, double* sample)
 {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool hit = false;
@@ -907,22 +923,30 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
             hit = true;
         }
     }
-    bool emit = hit && p.shadow_per_hit > 0 && !(p.d.flags & RTX_FLAG_NO_LIGHTING);
+    const bool lit = !(p.d.flags & RTX_FLAG_NO_LIGHTING) && s.n_lights > 0;
+    const uint32_t gather_per_hit = (lit && p.gather_traced) ? s.n_lights * p.gather_samples : 0u;
+    bool emit = hit && lit && (p.shadow_per_hit > 0 || p.gather_samples > 0);
     __shared__ uint32_t reserve_lds[kBlock / 64 + 2];
     // the workgroup's entries are laid out sample-major: entry (hit j of the workgroup, sample m)
     // sits at block_base + m * block_hits + j, so that for one m the lanes write neighbours
-    uint32_t block_hits = 0, block_base = 0, rank = 0;
+    uint32_t block_hits = 0, block_base = 0, rank = 0, gblock_base = 0;
     block_reserve(emit, shadow_count, p.shadow_per_hit, reserve_lds, &block_hits, &block_base, &rank);
+    if (gather_per_hit) block_reserve(emit, gather_count, gather_per_hit, reserve_lds, nullptr, &gblock_base);
     const uint32_t base = block_base + rank;
-    if (i < n) { shadow_base[i] = base; shadow_stride[i] = block_hits; }
-    if (emit && (unsigned long long)block_base + (unsigned long long)block_hits * p.shadow_per_hit <= p.shadow_cap) {
+    if (i < n) {
+        shadow_base[i] = base; shadow_stride[i] = block_hits;
+        if (gather_per_hit) gather_base[i] = gblock_base + rank;
+    }
+    const bool shadow_fits = (unsigned long long)block_base + (unsigned long long)block_hits * p.shadow_per_hit <= p.shadow_cap;
+    const bool gather_fits = (unsigned long long)gblock_base + (unsigned long long)block_hits * gather_per_hit <= p.gather_cap;
+    if (emit && shadow_fits && gather_fits) {
         d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
         Hit h;
         prim_full(s, (uint32_t)q.hit_prim[i], o, d, h);
         uint32_t slot = q.slot[i];
         Rng rng = ray_rng(p, q, i, slot);
         d3 from = h.position + (h.normal * p.d.bias);
-        uint32_t k = base;
+        uint32_t k = base, g = gblock_base + rank;
         for (uint32_t li = 0; li < s.n_lights; ++li) {
             const rtx_light& l = s.lights[li];
             uint32_t samples = l.multisample ? p.d.light_multisample_n * p.d.light_multisample_n : 1u;
@@ -934,15 +958,26 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
                 sq.dx[k] = lr.d.x; sq.dy[k] = lr.d.y; sq.dz[k] = lr.d.z;
                 sq.limit[k] = light_distance(l, lr);
             }
+            if (gather_per_hit) {
+                for (uint32_t gm = 0; gm < p.gather_samples; ++gm, g += block_hits) {
+                    // Ray lightRay(minRayResult.position, randomHemisphericalVector(normal)) (:503-505)
+                    Ray gr = make_ray(h.position, random_hemispherical_desktop(h.normal, rng));
+                    gq.ox[g] = gr.o.x; gq.oy[g] = gr.o.y; gq.oz[g] = gr.o.z;
+                    gq.dx[g] = gr.d.x; gq.dy[g] = gr.d.y; gq.dz[g] = gr.d.z;
+                }
+            } else {
+                rng.counter += 2u * p.gather_samples;   // directions whose nested call ends at the layer limit
+            }
         }
         q.counter[i] = rng.counter;       // the refraction child continues this stream
     }
 }
 
-// second half: direct lighting from the shadow results, blend, spawn children
+// second half: direct lighting from the shadow results, the gather's sum, blend, spawn children
 __global__ void __launch_bounds__(kBlock)
 k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, const uint32_t* shadow_base,
-                  const uint32_t* shadow_stride, RayQueue next, uint32_t* next_count, double* sample)
+                  const uint32_t* shadow_stride, GatherQueue gq, const uint32_t* gather_base, RayQueue next,
+                  uint32_t* next_count, double* sample)
 {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool spawn_t = false, spawn_r = false;
@@ -962,9 +997,10 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
         if (p.d.flags & RTX_FLAG_NO_LIGHTING) {
             local = material_color(s, m, h.u, h.v);
         } else {
-            d3 direct = mk(0, 0, 0);
+            d3 direct = mk(0, 0, 0), global = mk(0, 0, 0);
             uint32_t k = shadow_base[i];
             const uint32_t stride = shadow_stride[i];
+            uint32_t g = (p.gather_samples && p.gather_traced) ? gather_base[i] : 0u;
             for (uint32_t li = 0; li < s.n_lights; ++li) {
                 const rtx_light& l = s.lights[li];
                 uint32_t samples = l.multisample ? p.d.light_multisample_n * p.d.light_multisample_n : 1u;
@@ -979,8 +1015,29 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
                     }
                 }
                 direct = direct / (double)samples;          // inside the light loop (:498)
+                if (p.gather_samples) {                     // GLOBAL_LIGHTING (:499-524)
+                    for (uint32_t gm = 0; gm < p.gather_samples; ++gm, g += stride) {
+                        int32_t gp = p.gather_traced ? gq.hit_prim[g] : -1;
+                        if (gp >= 0) {
+                            // distance(origin, lightRayResult.position): a triangle's depth is that
+                            // very distance (Triangle.cpp:52-55), a sphere's position is o + d*t
+                            double t = gq.hit_depth[g];
+                            d3 gd = mk(gq.dx[g], gq.dy[g], gq.dz[g]);
+                            double dist = t;
+                            if ((s.prim_info[gp] & 3u) != RTX_PRIM_TRIANGLE) {
+                                d3 go = mk(gq.ox[g], gq.oy[g], gq.oz[g]);
+                                dist = distance3(go, go + (gd * t));
+                            }
+                            double att = light_attenuation(l, dist, p.d.attenuation);
+                            global = global + lighting(s, inv_dir, gd, h.normal, h.u, h.v, att, m, ld3(l.color));
+                        } else {
+                            global = global + (clear * 0.04);
+                        }
+                    }
+                    global = global / (double)p.d.global_samples;      // :523
+                }
             }
-            local = direct;
+            local = direct + global;
         }
         double trans = sample_scalar(s, m.transparency_fn, m.transparency, h.u, h.v);
         ni = sample_scalar(s, m.ni_fn, m.ni, h.u, h.v);

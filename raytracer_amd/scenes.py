@@ -14,7 +14,8 @@ from .host import HostScene, make_camera
 
 
 def render_desc(width, height, integrator=abi.INTEGRATOR_WHITTED, camera=None, n=1, light_n=1, max_depth=3,
-                bias=1e-3, clear=(0.0, 0.0, 0.0), flags=0, passes=1, first_pass=0, seed=0, frame=0, tile=None):
+                bias=1e-3, clear=(0.0, 0.0, 0.0), flags=0, passes=1, first_pass=0, seed=0, frame=0, tile=None,
+                global_samples=0):
     rd = abi.RenderDesc()
     rd.integrator = integrator
     rd.flags = flags
@@ -26,6 +27,7 @@ def render_desc(width, height, integrator=abi.INTEGRATOR_WHITTED, camera=None, n
     rd.max_depth = max_depth
     rd.first_pass, rd.passes = first_pass, passes
     rd.frame, rd.seed = frame, seed
+    rd.global_samples = global_samples          # MONTE_CARLO_SAMPLES of the Whitted variant, Desktop :73
     rd.bias = bias
     rd.clear_color[:] = clear
     rd.attenuation[:] = (1.0, 0.09, 0.032)      # LIGHT_CONTSTANT/LINEAR/QUADRATIC, Desktop :78-80
