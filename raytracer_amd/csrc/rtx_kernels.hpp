@@ -435,32 +435,64 @@ RTX_DEV bool member_through_point(const DScene& s, uint32_t shape, d3 p, d3 o, d
     return at < end && s.prim_leaf_ids[at] == leaf;
 }
 
-// Cheapest existence proof, for a point p = o + d*t (t >= 0) of the ray.  When p lies inside
-// the cell of a KD leaf -- inside every ancestor's box and on the leaf's side of every
-// ancestor's split plane -- by a margin far above the rounding error of the slab arithmetic
-// (margin ~1e-9 of the scene size, errors ~1e-15), traverseKDTree provably reaches that
-// leaf: at each ancestor the box is hit over a parameter interval of positive length around
-// t, and since the coordinate along the split axis is monotone in the parameter, either the
-// entry point or the exit point is on p's side of the plane by more than the error, which is
-// exactly what KDTree.cpp:171-194 tests.  The leaf is located from the deepest node that
-// covers all leaves of the shape, so only a few levels are walked and only with (axis, value).
+// Cheapest existence proof.  When some point p = o + d*t (t > 0) of the ray lies inside the
+// cell of a KD leaf -- inside every ancestor's box and on the leaf's side of every ancestor's
+// split plane -- by a margin far above the rounding error of the slab arithmetic (margin
+// ~1e-9 of the scene size, errors ~1e-15), traverseKDTree provably reaches that leaf: at each
+// ancestor the box is hit over a parameter interval of positive length around t, and since
+// the coordinate along the split axis is monotone in the parameter, either the entry point or
+// the exit point is on p's side of the plane by more than the error, which is exactly what
+// KDTree.cpp:171-194 tests.  The leaf is located from the deepest node that covers all leaves
+// of the shape, so only a few levels are walked and only with (axis, value).
+// The point tried first is the hit point.  A hit point ON a face of its cell (a floor that
+// is the bottom of the scene box, geometry lying in a split plane) cannot pass; the ray
+// then reached it from inside the cell or not at all, so the second try is the point a
+// little earlier on the ray, as far back as the offending faces require.
 // A `false` only means "not shown this way".
-RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 p, double margin)
+RTX_DEV int32_t locate_leaf(const DScene& s, int32_t node, d3 p)
 {
-    int32_t node = s.prim_lca[shape];
     while (node >= 0) {
         const KdSplit k = s.kd_split[node];
         node = pick(p, k.lesser_axis & 3) <= k.value ? (k.lesser_axis >> 2) : k.greater;
     }
-    uint32_t leaf = (uint32_t)~node;
-    const PrimBox* c = s.leaf_cell + leaf;
-    bool inside = p.x - margin >= c->bmin[0] && p.x + margin <= c->bmax[0] &&
-                  p.y - margin >= c->bmin[1] && p.y + margin <= c->bmax[1] &&
-                  p.z - margin >= c->bmin[2] && p.z + margin <= c->bmax[2];
-    if (!inside) return false;
+    return node;
+}
+
+RTX_DEV bool leaf_holds(const DScene& s, uint32_t shape, uint32_t leaf)
+{
     const uint32_t first = s.prim_leaf_first[shape], end = s.prim_leaf_first[shape + 1];
     uint32_t at = lower_bound_u32(s.prim_leaf_ids, first, end, leaf);
     return at < end && s.prim_leaf_ids[at] == leaf;
+}
+
+RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 o, d3 d, double t, double margin)
+{
+    const int32_t lca = s.prim_lca[shape];
+    d3 p = o + (d * t);
+    uint32_t leaf = (uint32_t)~locate_leaf(s, lca, p);
+    const PrimBox* c = s.leaf_cell + leaf;
+    // how far each coordinate is short of being `margin` inside the cell (<= 0: fine)
+    const double lx = (c->bmin[0] + margin) - p.x, hx = p.x - (c->bmax[0] - margin);
+    const double ly = (c->bmin[1] + margin) - p.y, hy = p.y - (c->bmax[1] - margin);
+    const double lz = (c->bmin[2] + margin) - p.z, hz = p.z - (c->bmax[2] - margin);
+    if (lx <= 0.0 && hx <= 0.0 && ly <= 0.0 && hy <= 0.0 && lz <= 0.0 && hz <= 0.0) return leaf_holds(s, shape, leaf);
+    // step back along the ray: a face the point is too close to must be one the ray leaves through
+    double back = 0.0;
+    if (lx > 0.0) { if (!(d.x < 0.0)) return false; back = __builtin_fmax(back, (lx + margin) / -d.x); }
+    if (hx > 0.0) { if (!(d.x > 0.0)) return false; back = __builtin_fmax(back, (hx + margin) / d.x); }
+    if (ly > 0.0) { if (!(d.y < 0.0)) return false; back = __builtin_fmax(back, (ly + margin) / -d.y); }
+    if (hy > 0.0) { if (!(d.y > 0.0)) return false; back = __builtin_fmax(back, (hy + margin) / d.y); }
+    if (lz > 0.0) { if (!(d.z < 0.0)) return false; back = __builtin_fmax(back, (lz + margin) / -d.z); }
+    if (hz > 0.0) { if (!(d.z > 0.0)) return false; back = __builtin_fmax(back, (hz + margin) / d.z); }
+    const double t2 = t - back;
+    if (!(t2 > 0.0)) return false;
+    p = o + (d * t2);
+    leaf = (uint32_t)~locate_leaf(s, lca, p);
+    c = s.leaf_cell + leaf;
+    bool inside = p.x - margin >= c->bmin[0] && p.x + margin <= c->bmax[0] &&
+                  p.y - margin >= c->bmin[1] && p.y + margin <= c->bmax[1] &&
+                  p.z - margin >= c->bmin[2] && p.z + margin <= c->bmax[2];
+    return inside && leaf_holds(s, shape, leaf);
 }
 
 // Optimistic form: the BVH walk treats every geometric candidate as genuine, so its loop
@@ -560,7 +592,7 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     if (best_prim < 0) return true;                 // no geometric candidate at all: the reference finds none either
     if (tie) return false;
     d3 at = o + (d * best_depth);
-    if (member_by_cell(s, best_shape, at, abs_margin)) return true;
+    if (member_by_cell(s, best_shape, o, d, best_depth, abs_margin)) return true;
     return member_through_point<COUNT>(s, best_shape, at, o, d, inv, w) ||
            first_visited_position<COUNT>(s, best_shape, o, d, inv, w) != kNoPosition;
 }
