@@ -202,10 +202,14 @@ enum {
     RTX_FLAG_SORT_MATERIAL   = 1u << 9, /* pathTrace levels are shaded in material order
                                            (rays binned by the material they hit) instead
                                            of queue order; same image                      */
-    RTX_FLAG_GLOBAL_LIGHTING = 1u << 10 /* Whitted with GLOBAL_LIGHTING: the hemisphere gather
+    RTX_FLAG_GLOBAL_LIGHTING = 1u << 10,/* Whitted with GLOBAL_LIGHTING: the hemisphere gather
                                            inside the light loop
                                            (Raytracer-Noah-Desktop.cpp:69,499-524), with
                                            rtx_render_desc.global_samples = MONTE_CARLO_SAMPLES */
+    RTX_FLAG_REFILL_LANES    = 1u << 11 /* the BVH walk refills finished lanes from the queue
+                                           instead of keeping one ray per lane for the life of
+                                           a wavefront (same results; fewer idle lanes but
+                                           measured slower, for comparison)                   */
 };
 
 /* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;
@@ -261,6 +265,11 @@ typedef struct rtx_stats {
     double ms_total;
     uint32_t traverse_launches;
     uint32_t max_queue;
+    /* SIMD efficiency of the traversal launches, with RTX_FLAG_COUNTERS: a step is a node visit
+       or a shape test; lane_steps sums them over all rays, wave_steps sums 64 * (the largest
+       lane count of each wavefront).  lane_steps / wave_steps = fraction of lanes doing work. */
+    uint64_t wave_steps;
+    uint64_t lane_steps;
 } rtx_stats;
 
 typedef struct rtx_scene rtx_scene;

@@ -36,6 +36,7 @@ FLAG_STAGE_TIMES = 1 << 7
 FLAG_RENDER_WALK = 1 << 8
 FLAG_SORT_MATERIAL = 1 << 9
 FLAG_GLOBAL_LIGHTING = 1 << 10
+FLAG_REFILL_LANES = 1 << 11
 
 TONEMAP_NONE, TONEMAP_CBRT = 0, 1
 
@@ -129,6 +130,7 @@ class Stats(C.Structure):
         ("ms_generate", C.c_double), ("ms_traverse", C.c_double), ("ms_shade", C.c_double),
         ("ms_shadow", C.c_double), ("ms_resolve", C.c_double), ("ms_total", C.c_double),
         ("traverse_launches", C.c_uint32), ("max_queue", C.c_uint32),
+        ("wave_steps", C.c_uint64), ("lane_steps", C.c_uint64),
     ]
 
     @property

@@ -76,6 +76,8 @@ struct Workspace {
     ShadowQueue sq;
     GatherQueue gq;
     uint32_t* gather_index = nullptr;       // per ray: first gather entry
+    uint32_t* cand = nullptr;               // per traced ray: candidate left by k_trace_refill for k_verify
+    size_t cand_capacity = 0;
     uint32_t* shadow_index = nullptr;       // per ray: first shadow entry
     uint32_t* shadow_stride = nullptr;      // per ray: distance between its entries
     uint32_t* perm = nullptr;               // shading order (material sort)
@@ -90,6 +92,7 @@ struct Workspace {
         if (base) (void)hipFree(base);
         if (shadow_base_mem) (void)hipFree(shadow_base_mem);
         if (gather_base_mem) (void)hipFree(gather_base_mem);
+        if (cand) (void)hipFree(cand);
         if (counts) (void)hipFree(counts);
         if (bins) (void)hipFree(bins);
         if (work) (void)hipFree(work);
@@ -124,20 +127,23 @@ struct rtx_scene {
     uint32_t kd_depth = 0;
     uint32_t bvh_depth = 0;
     bool may_refract = false;       // some material can have transparency != 0 (rayTrace spawns a child then)
+    int compute_units = 0;
+    uint32_t refill_range = 256;    // most rays a wave of the refilled walk owns
+    uint32_t refill_at = 16;        // parked lanes that trigger a store + fetch
 };
 
 namespace {
 
-int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap, size_t gather_cap)
+int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap, size_t gather_cap, bool with_cand)
 {
     Workspace& w = sc->ws;
     if (!w.counts) {
-        HIP_TRY(hipMalloc(&w.counts, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&w.work, 10 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&w.counts, 8 * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&w.work, 12 * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc(&w.bins, 2 * kBins * sizeof(uint32_t)));
         HIP_TRY(hipMemset(w.bins, 0, 2 * kBins * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc(&w.host_counts, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc(&w.host_work, 10 * sizeof(unsigned long long)));
+        HIP_TRY(hipHostMalloc(&w.host_work, 12 * sizeof(unsigned long long)));
     }
     if (cap > w.capacity) {
         if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.capacity = 0; }
@@ -183,6 +189,12 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap, size_t gather
         g.hit_depth = carve<double>(p, gather_cap);
         g.hit_prim = carve<int32_t>(p, gather_cap);
         w.gather_capacity = gather_cap;
+    }
+    const size_t cand_cap = with_cand ? std::max(cap, std::max(shadow_cap, gather_cap)) : 0;
+    if (cand_cap > w.cand_capacity) {
+        if (w.cand) { HIP_TRY(hipFree(w.cand)); w.cand = nullptr; w.cand_capacity = 0; }
+        HIP_TRY(hipMalloc(&w.cand, cand_cap * sizeof(uint32_t)));
+        w.cand_capacity = cand_cap;
     }
     return RTX_OK;
 }
@@ -339,6 +351,13 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     rtx_scene* sc = new rtx_scene();
     sc->kd_depth = kd_depth;
     (void)hipGetDevice(&sc->device);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess) sc->compute_units = prop.multiProcessorCount;
+        if (sc->compute_units < 1) sc->compute_units = 256;
+        if (const char* env = std::getenv("RTX_REFILL_AT")) { long v = std::atol(env); if (v >= 1 && v <= 64) sc->refill_at = (uint32_t)v; }
+        if (const char* env = std::getenv("RTX_REFILL_RANGE")) { long v = std::atol(env); if (v >= 64 && v <= (1 << 20)) sc->refill_range = (uint32_t)v / 64 * 64; }
+    }
     DScene& d = sc->d;
     std::memset(&d, 0, sizeof d);
     d.root = s->kd_root;
@@ -623,6 +642,27 @@ static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const
     Counters g;
     g.c = count ? sc->ws.work : nullptr;
     dim3 grid = trace_grid_for(n), block(kTraceBlock);
+    if (mode >= 3 && (flags & RTX_FLAG_REFILL_LANES) && n <= sc->ws.cand_capacity) {
+        // lanes refilled from the wave's own range of the queue; ranges shrink for small launches
+        // so that every resident wave slot gets several
+        const int anyhit = limit ? 1 : 0;
+        const uint64_t slots = (uint64_t)sc->compute_units * 16u;
+        const uint32_t rays_per_wave = (uint32_t)std::min<uint64_t>(sc->refill_range, std::max<uint64_t>(64, ((uint64_t)n / (slots * 4)) / 64 * 64));
+        dim3 pgrid((unsigned)(((uint64_t)n + rays_per_wave - 1) / rays_per_wave));
+#define RTX_LAUNCH_REFILL(COUNT, ANYHIT)                                                                              \
+    hipLaunchKernelGGL((k_trace_refill<COUNT, ANYHIT>), pgrid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
+                       n_device, sc->refill_at, rays_per_wave, hit_prim, hit_depth, sc->ws.cand, g)
+        if (count) { if (anyhit) RTX_LAUNCH_REFILL(true, true); else RTX_LAUNCH_REFILL(true, false); }
+        else { if (anyhit) RTX_LAUNCH_REFILL(false, true); else RTX_LAUNCH_REFILL(false, false); }
+#undef RTX_LAUNCH_REFILL
+        HIP_TRY(hipGetLastError());
+        if (count) hipLaunchKernelGGL(k_verify<true>, grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, n, n_device,
+                                      sc->ws.cand, hit_prim, hit_depth, g);
+        else hipLaunchKernelGGL(k_verify<false>, grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, n, n_device,
+                                sc->ws.cand, hit_prim, hit_depth, g);
+        HIP_TRY(hipGetLastError());
+        return RTX_OK;
+    }
 #define RTX_LAUNCH_TRACE(COUNT, MODE)                                                                                  \
     hipLaunchKernelGGL((k_trace_pool<COUNT, MODE>), grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
                        n_device, linear, hit_prim, hit_depth, g)
@@ -705,7 +745,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     if (queue_cap * std::max<uint64_t>(gather_per_hit0, 1) > 0xffffffffull || queue_cap * (uint64_t)std::max<uint32_t>(shadow_per_hit, 1) > 0xffffffffull)
         return fail(RTX_ERR_LIMIT, "shadow / gather queue of one chunk exceeds 2^32 entries: lower RTX_MAX_PATHS");
     int rc = ensure_workspace(sc, queue_cap, whitted ? queue_cap * std::max<uint32_t>(shadow_per_hit, 1) : 0,
-                              (size_t)(queue_cap * gather_per_hit0));
+                              (size_t)(queue_cap * gather_per_hit0), (rd->flags & RTX_FLAG_REFILL_LANES) != 0);
     if (rc != RTX_OK) return rc;
     Workspace& w = sc->ws;
     hipStream_t st = sc->stream;
@@ -718,7 +758,10 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     StageTimer timer(stats != nullptr && (rd->flags & RTX_FLAG_STAGE_TIMES), st);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, st)); }
-    if (count_work) HIP_TRY(hipMemsetAsync(w.work, 0, 8 * sizeof(unsigned long long), st));
+    if (count_work) {
+        HIP_TRY(hipMemsetAsync(w.work, 0, 8 * sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(w.work + 10, 0, 2 * sizeof(unsigned long long), st));
+    }
     const bool single_level = whitted && !sc->may_refract && !(rd->flags & RTX_FLAG_WHITTED_REFLECT);
     if (single_level) HIP_TRY(hipMemsetAsync(w.work + 8, 0, 2 * sizeof(unsigned long long), st));
 
@@ -827,6 +870,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     }
     if (count_work) {
         HIP_TRY(hipMemcpyAsync(w.host_work, w.work, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(w.host_work + 10, w.work + 10, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     }
     if (single_level) HIP_TRY(hipMemcpyAsync(w.host_work + 8, w.work + 8, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (stats) HIP_TRY(hipEventRecord(ev1, st));
@@ -842,6 +886,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
             local.branch_visits = w.host_work[0]; local.leaf_visits = w.host_work[1]; local.aabb_tests = w.host_work[2];
             local.triangle_tests = w.host_work[3]; local.sphere_tests = w.host_work[4]; local.hits_accepted = w.host_work[5];
             local.content_tests = w.host_work[6]; local.fallback_rays = w.host_work[7];
+            local.wave_steps = w.host_work[10]; local.lane_steps = w.host_work[11];
         }
         *stats = local;
     }

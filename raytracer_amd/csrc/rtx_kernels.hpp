@@ -614,6 +614,26 @@ RTX_DEV void add_counters(Counters g, const Work<true>& w)
 }
 RTX_DEV void add_counters(Counters, const Work<false>&) {}
 
+// SIMD efficiency of a walk that keeps one ray per lane for the life of the wave: the wave
+// runs as long as its busiest lane.  Steps = node visits + shape tests; c[10] sums 64 * (the
+// wave's largest lane count), c[11] all lanes' counts.
+RTX_DEV void add_static_efficiency(Counters g, const Work<true>& w)
+{
+    if (!g.c) return;
+    uint32_t steps = w.content / 2u + w.branch + w.tri + w.sph;
+    uint32_t mx = steps;
+    const unsigned long long active = __ballot(1);      // the last wave of a launch may be partial
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t other = (uint32_t)__shfl_xor((int)mx, off, 64);
+        if ((active >> (lane ^ (uint32_t)off)) & 1ull) mx = max(mx, other);
+    }
+    if (lane == 0) atomicAdd(g.c + 10, 64ull * mx);
+    atomicAdd(g.c + 11, (unsigned long long)steps);
+}
+RTX_DEV void add_static_efficiency(Counters, const Work<false>&) {}
+
 // shootRay for caller-supplied rays (rtx_trace_closest).  MODE 0 walks in the reference's
 // order and reports leaf sequences; MODE 1 (culled KD walk) and 3 (BVH) are the render
 // path's walks, for which the leaf outputs describe nothing the reference does.
@@ -687,6 +707,215 @@ k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__
     }
     if (hit_prim) hit_prim[i] = bp;
     hit_depth[i] = bd;
+    add_counters(g, w);
+    add_static_efficiency(g, w);
+}
+
+// ---- the BVH walk with lanes refilled from the queue ---------------------------------------------
+// Rays of one wave need very different numbers of steps (bounce rays: a third of the lanes
+// busy on average with one ray per lane), and a wave runs as long as its busiest lane.  Here a
+// wave owns `rays_per_wave` consecutive rays of the queue: a lane whose ray is finished parks
+// it, and once `refill_at` lanes of the wave are parked they all store their candidates
+// together and take the next rays of the wave's range.  Storing and fetching in groups keeps
+// those sections, which run with only the parked lanes active, a small part of the
+// instruction stream.  Ranges are handed out by the hardware's own workgroup dispatch, which
+// balances the load; a shared ray counter was tried and is slower (an atomic on one address
+// completes at under 10^8 a second across the eight XCDs, below the rate at which waves ask).
+// The membership verification is a chain of dependent loads; inside this loop it would stall
+// the whole wave once per group, so it is left to k_verify, which runs afterwards over the
+// queue with every lane busy.  `cand` tells it what to do per ray:
+constexpr uint32_t kCandSettled = 0xffffffffu;      // no geometric candidate: the miss is final
+constexpr uint32_t kCandReference = 0xfffffffeu;    // not walked (non-finite ray): take the reference-order walk
+constexpr uint32_t kCandTie = 0x80000000u;          // flag: another shape ties at the winning depth
+// otherwise: the winning candidate's shape id.
+// The walk and its culls are those of trace_lane_bvh; with k_verify the results are identical.
+template <bool COUNT, bool ANYHIT>
+__global__ void __launch_bounds__(kTraceBlock)
+k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
+               const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
+               const double* __restrict__ limit, uint32_t n, const uint32_t* __restrict__ n_device, uint32_t refill_at,
+               uint32_t rays_per_wave, int32_t* hit_prim, double* hit_depth, uint32_t* cand, Counters g)
+{
+    __shared__ int32_t stack_mem[kStack * kTraceBlock];
+    int32_t* const stack = stack_mem + threadIdx.x;
+    const uint32_t lane = threadIdx.x;              // one wave per workgroup
+    if (n_device) n = min(n, *n_device);
+    if ((unsigned long long)blockIdx.x * rays_per_wave >= n) return;
+    bool have = false;          // this lane is walking a ray
+    bool pending = false;       // this lane holds a ray whose result is not stored yet
+    bool exact = true;          // the ray may take the culled walk (finite origin and 1/direction)
+    // the unassigned rest of this wave's range (wave-uniform)
+    const unsigned long long first = (unsigned long long)blockIdx.x * rays_per_wave;
+    uint32_t cur = (uint32_t)min(first, (unsigned long long)n);
+    const uint32_t end = (uint32_t)min(first + rays_per_wave, (unsigned long long)n);
+    bool exhausted = cur == end;
+    uint32_t ray = 0;
+    d3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv = mk(0, 0, 0);
+    double lim = kInf, abs_margin = 0.0, bound2 = kInf, best_depth = kInf;
+    int32_t best_prim = -1, node = 0;
+    (void)lim;
+    uint32_t best_shape = 0;
+    bool tie = false;
+    int sp = 0;
+    uint32_t leaf_k = 0;        // next shape of the leaf being scanned
+    Work<COUNT> w;
+    unsigned long long wave_iters = 0, lane_iters = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle == 64u || (!exhausted && n_idle >= refill_at)) {
+            if (pending && !have) {
+                if (hit_prim) hit_prim[ray] = best_prim;
+                hit_depth[ray] = best_depth;
+                cand[ray] = !exact ? kCandReference : (best_prim < 0 ? kCandSettled : (best_shape | (tie ? kCandTie : 0u)));
+                pending = false;
+            }
+            if (exhausted) break;                   // here every lane is parked and has retired
+            if (!have) {
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t idx = cur + below;
+                if (idx < end) {
+                    ray = idx;
+                    o = mk(ox[idx], oy[idx], oz[idx]); d = mk(dx[idx], dy[idx], dz[idx]);
+                    if constexpr (ANYHIT) lim = limit[idx];
+                    inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                    exact = isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
+                    abs_margin = 1e-9 * (s.scene_scale + __builtin_fmax(fabs(o.x), __builtin_fmax(fabs(o.y), fabs(o.z))));
+                    // closest hit: squared distance bound; any hit: the light distance itself,
+                    // compared with the largest per-axis gap
+                    bound2 = ANYHIT ? lim * (1.0 + 1e-7) + abs_margin : kInf;
+                    best_prim = -1; best_depth = kInf; best_shape = 0; tie = false;
+                    sp = 0; node = s.bvh_root; leaf_k = 0;
+                    pending = true;
+                    have = exact && s.bvh_root != kBvhEmpty;
+                }
+            }
+            cur = min(end, cur + n_idle);
+            exhausted = cur == end;
+            continue;
+        }
+        if constexpr (COUNT) { wave_iters++; lane_iters += have ? 1u : 0u; }
+        if (have) {
+            bool pop = true;
+            if (node >= 0) {
+                // one node = four 16-byte loads
+                const float4* nd = reinterpret_cast<const float4*>(s.bvh_nodes + node);
+                const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                const d3 lb0 = mk(n0.x, n0.y, n0.z), lb1 = mk(n0.w, n1.x, n1.y);
+                const d3 rb0 = mk(n1.z, n1.w, n2.x), rb1 = mk(n2.y, n2.z, n2.w);
+                double lmin, lmax, rmin, rmax, lgap, rgap;
+                slab_and_gap<ANYHIT>(lb0, lb1, o, inv, lmin, lmax, lgap);
+                slab_and_gap<ANYHIT>(rb0, rb1, o, inv, rmin, rmax, rgap);
+                if constexpr (COUNT) w.content += 2;
+                const bool hl = lmin <= lmax && lmax >= 0.0 && !(lgap > bound2);
+                const bool hr = rmin <= rmax && rmax >= 0.0 && !(rgap > bound2);
+                const int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+                if (hl && hr) {
+                    const bool left_first = lmin <= rmin;
+                    stack[sp * kTraceBlock] = left_first ? right : left;
+                    ++sp;
+                    node = left_first ? left : right;
+                    pop = false;
+                } else if (hl) { node = left; pop = false; }
+                else if (hr) { node = right; pop = false; }
+            } else {
+                // one shape of the leaf per iteration: lanes at nodes and lanes in leaves share
+                // every iteration, so a leaf must not hold the others up for its whole run
+                const uint32_t code = (uint32_t)~node;
+                const BvhPrim* q = s.bvh_prims + (code >> 3) + leaf_k;
+                const uint32_t count = (code & 7u) + 1u;
+                ++leaf_k;
+                pop = leaf_k >= count;
+                do {
+                    // Shape::rayAABB && rayHit (KDTree.cpp:208-211) commute: rayHit first, and the
+                    // shape's box is only fetched for a hit that could change the result
+                    const d3 ta = ld3(q->p), tb = ld3(q->p + 3), tc = ld3(q->p + 6);
+                    const uint32_t shape = q->shape, info = q->info;
+                    const uint32_t type = info & 3u, idx = info >> 2;
+                    double depth = kInf;
+                    uint32_t rp = shape;
+                    bool hit;
+                    if (type == RTX_PRIM_TRIANGLE) {
+                        if constexpr (COUNT) w.tri++;
+                        hit = triangle_depth(ta, tb, tc, o, d, depth);
+                    } else if (type == RTX_PRIM_SPHERE) {
+                        if constexpr (COUNT) w.sph++;
+                        hit = sphere_t(ld3(s.sph_center + 3 * (size_t)idx), s.sph_r2[idx], o, d, depth);
+                    } else {
+                        if constexpr (COUNT) w.sph += 2;
+                        hit = biconvex_depth(s, idx, o, d, depth, rp);
+                    }
+                    if (!hit) break;
+                    if (ANYHIT ? !(depth <= lim) : !(depth <= best_depth)) break;
+                    double tmin, tmax;
+                    slab_finite(s.prim_box + shape, o, inv, tmin, tmax);
+                    if constexpr (COUNT) w.aabb++;
+                    if (!(tmin <= tmax && tmax >= 0.0)) break;
+                    if constexpr (ANYHIT) {
+                        best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; sp = 0; pop = true;
+                    } else if (depth < best_depth) {
+                        if constexpr (COUNT) w.accepted++;
+                        best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; tie = false;
+                        const double bd = best_depth * (1.0 + 1e-7) + abs_margin;
+                        bound2 = bd * bd;
+                    } else if ((int32_t)rp != best_prim) {
+                        tie = true;
+                    }
+                } while (false);
+                if (pop) leaf_k = 0;
+            }
+            if (pop) {
+                if (sp == 0) have = false;
+                else { --sp; node = stack[sp * kTraceBlock]; }
+            }
+        }
+    }
+    add_counters(g, w);
+    if constexpr (COUNT) {
+        if (g.c) {
+            if (lane == 0) atomicAdd(g.c + 10, 64ull * wave_iters);
+            atomicAdd(g.c + 11, lane_iters);
+        }
+    }
+}
+
+// Second half of the refilled walk: certify each ray's optimistic answer against the reference's
+// KD tree, or take the reference-order walk for it (ties, failed certificates, non-finite rays).
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock)
+k_verify(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
+         const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
+         uint32_t n, const uint32_t* __restrict__ n_device, const uint32_t* __restrict__ cand, int32_t* hit_prim,
+         double* hit_depth, Counters g)
+{
+    __shared__ int32_t stack[kStack * kTraceBlock];
+    uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
+    if (n_device) n = min(n, *n_device);
+    if (i >= n) return;
+    const uint32_t c = cand[i];
+    if (c == kCandSettled) return;
+    const d3 o = mk(ox[i], oy[i], oz[i]), d = mk(dx[i], dy[i], dz[i]);
+    Work<COUNT> w;
+    bool ok = false;
+    if (c != kCandReference && !(c & kCandTie)) {
+        const uint32_t shape = c;
+        const double depth = hit_depth[i];
+        const d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        const double abs_margin = 1e-9 * (s.scene_scale + __builtin_fmax(fabs(o.x), __builtin_fmax(fabs(o.y), fabs(o.z))));
+        ok = member_by_cell(s, shape, o, d, depth, abs_margin);
+        if (!ok) {
+            d3 at = o + (d * depth);
+            ok = member_through_point<COUNT>(s, shape, at, o, d, inv, w) ||
+                 first_visited_position<COUNT>(s, shape, o, d, inv, w) != kNoPosition;
+        }
+    }
+    if (!ok) {
+        if constexpr (COUNT) w.fallback++;
+        int32_t bp = -1; double bd = kInf;
+        trace_lane<COUNT>(s, o, d, false, stack + threadIdx.x, bp, bd, w, nullptr, 0);
+        if (hit_prim) hit_prim[i] = bp;
+        hit_depth[i] = bd;
+    }
     add_counters(g, w);
 }
 

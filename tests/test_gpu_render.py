@@ -96,7 +96,14 @@ def test_culled_walk_gives_identical_images(gpu, name, make, kw):
         a, sa = ds.render(fast)         # BVH candidates + membership verification (default)
         m, sm = ds.render(mid)          # reference KD tree walked with culling
         b, sb = ds.render(slow)         # reference order, nothing skipped
+        fast.flags |= abi.FLAG_REFILL_LANES
+        c, sc = ds.render(fast)         # BVH walk with finished lanes refilled from the queue
     assert np.array_equal(a, b)
+    assert np.array_equal(c, b)
+    _same_ray_counts(sc, sb)
+    for k in ("content_tests", "triangle_tests", "sphere_tests", "aabb_tests", "hits_accepted", "fallback_rays"):
+        assert getattr(sc, k) == getattr(sa, k), k       # the same walk per ray, only scheduled differently
+    assert 0 < sa.lane_steps <= sa.wave_steps and 0 < sc.lane_steps <= sc.wave_steps
     assert np.array_equal(m, b)
     _same_ray_counts(sa, sb)
     _same_ray_counts(sm, sb)

@@ -61,6 +61,8 @@ def main():
     ap.add_argument("names", nargs="*", default=["c1", "c2", "c3", "c4w", "c4p"])
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--sort-material", action="store_true", help="shade pathTrace levels in material order")
+    ap.add_argument("--refill-lanes", action="store_true", help="BVH walk with finished lanes refilled from the queue")
+    ap.add_argument("--brief", action="store_true", help="print only config, rays/s, ms/frame and stage times")
     args = ap.parse_args()
     import torch
     from raytracer_amd import abi, device
@@ -95,6 +97,7 @@ def main():
             fb.zero_()
             rd = rd_of(1 + f)
             rd.flags |= abi.FLAG_STAGE_TIMES | (abi.FLAG_SORT_MATERIAL if args.sort_material else 0)
+            rd.flags |= abi.FLAG_REFILL_LANES if args.refill_lanes else 0
             st = ds.render_device(rd, fb.data_ptr())
             for k in rays:
                 rays[k] += getattr(st, k)
@@ -111,6 +114,9 @@ def main():
                "host_first_frame_s": round(t_host, 3), "upload_s": round(t_up, 3),
                "host_rebuild_s_per_frame": round(host_s / frames, 3) if animated else None,
                "finite": bool(torch.isfinite(fb).all().item())}
+        out["refill_lanes"] = args.refill_lanes
+        if args.brief:
+            out = {k: out[k] for k in ("config", "refill_lanes", "Mrays_per_s", "ms_per_frame", "stage_ms")}
         print(json.dumps(out), flush=True)
         ds.close()
         scene.close()
