@@ -293,3 +293,42 @@ def test_full_size_bench_workload_properties(gpu):
         ds.render_device(rd(passes=2), fb.data_ptr())
         assert torch.equal(fb, img_bvh + img_bvh)
         assert torch.isfinite(img_bvh).all() and float(img_bvh.max()) > 0.5
+
+
+def test_degenerate_scenes(gpu):
+    """No shapes, no lights, lights without shapes, several lights of all three kinds (the
+    running `direct /= samples` of Raytracer-Noah-Desktop.cpp:498), with and without the gather:
+    ray counts equal the oracle's and the images match."""
+    from raytracer_amd.host import HostScene, make_camera
+    cam = make_camera((0.0, 1.0, 5.0), (0.0, 0.0, 0.0))
+
+    def empty():
+        return HostScene()
+
+    def only_light():
+        s = HostScene()
+        s.point_light((0.0, 5.0, 0.0))
+        return s
+
+    def unlit_sphere():
+        s = HostScene()
+        s.sphere((0.0, 0.0, 0.0), 1.0, s.material("Red"))
+        return s
+
+    def three_lights():
+        s = unlit_sphere()
+        s.point_light((0.0, 5.0, 0.0))
+        s.directional_light((-1.0, -1.0, -1.0))
+        s.square_light((0.0, 5.0, 0.0), (0.0, -1.0, 0.0), 1.0, 1.0)
+        return s
+
+    for make, kw in ((empty, {}), (only_light, {}), (unlit_sphere, {}), (three_lights, {}),
+                     (three_lights, dict(flags=abi.FLAG_GLOBAL_LIGHTING, global_samples=3))):
+        desc = make().frame(0.0)
+        for integrator in (abi.INTEGRATOR_WHITTED, abi.INTEGRATOR_PATH):
+            rd = scenes.render_desc(33, 17, integrator=integrator, camera=cam, n=2, light_n=2, max_depth=2,
+                                    clear=(0.1, 0.2, 0.3), **kw)
+            img, stats, ref, ref_stats = _both(gpu, desc, rd)
+            _same_ray_counts(stats, ref_stats)
+            assert stats.rays_primary == 33 * 17 * 4
+            assert np.isfinite(img).all() and rel_err(img, ref).max() < REL_TOL, make.__name__
