@@ -189,11 +189,14 @@ class HostScene:
 
     # ---- per frame
     def frame(self, current_time=0.0):
-        """redoAABBs + buildKDTree + flatten; returns the rtx_scene_desc (valid until the next call)."""
+        """redoAABBs + buildKDTree + flatten; returns the rtx_scene_desc (valid until the next call
+        or close()).  The description points into arrays this scene owns, so it keeps a reference
+        to the scene: holding the description alone is enough to keep them alive."""
         p = self._L.rth_frame(self._h, float(current_time))
         if not p:
             raise RuntimeError(self._L.rth_scene_error(self._h).decode())
         self.desc = p.contents
+        self.desc._owner = self
         return self.desc
 
     def set_kd_builder(self, builder="flat", threads=0):
