@@ -127,6 +127,7 @@ struct rtx_scene {
     uint32_t kd_depth = 0;
     uint32_t bvh_depth = 0;
     bool may_refract = false;       // some material can have transparency != 0 (rayTrace spawns a child then)
+    std::vector<uint8_t> light_multisample;     // Light::multisample per light, kept on the host
     int compute_units = 0;
     uint32_t refill_range = 256;    // most rays a wave of the refilled walk owns
     uint32_t refill_at = 16;        // parked lanes that trigger a store + fetch
@@ -390,6 +391,7 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     }
     for (uint32_t i = 0; i < s->n_materials; ++i)
         if (s->materials[i].transparency != 0.0 || s->materials[i].transparency_fn.kind != RTX_SAMPLER_CONST) sc->may_refract = true;
+    for (uint32_t i = 0; i < s->n_lights; ++i) sc->light_multisample.push_back(s->lights[i].multisample ? 1 : 0);
     BvhBuild bvh;
     std::future<void> bvh_done = std::async(std::launch::async, [&]() { build_bvh(boxes, s->n_shapes, bvh); });
     struct Join { std::future<void>& f; ~Join() { if (f.valid()) f.wait(); } } join_bvh{bvh_done};
@@ -704,10 +706,8 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     uint32_t nn = n * n;
     uint32_t shadow_per_hit = 0;
     if (whitted && !(rd->flags & RTX_FLAG_NO_LIGHTING)) {
-        std::vector<rtx_light> lights(sc->d.n_lights);
-        if (!lights.empty()) HIP_TRY(hipMemcpy(lights.data(), sc->d.lights, lights.size() * sizeof(rtx_light), hipMemcpyDeviceToHost));
-        for (const rtx_light& l : lights)
-            shadow_per_hit += l.multisample ? rd->light_multisample_n * rd->light_multisample_n : 1u;
+        for (uint8_t multisample : sc->light_multisample)
+            shadow_per_hit += multisample ? rd->light_multisample_n * rd->light_multisample_n : 1u;
     }
     p.shadow_per_hit = shadow_per_hit;
     // GLOBAL_LIGHTING: globalSamples per light at a level (Raytracer-Noah-Desktop.cpp:500); MAXBOUNCES = 0
@@ -756,7 +756,12 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     rtx_stats local;
     std::memset(&local, 0, sizeof local);
     StageTimer timer(stats != nullptr && (rd->flags & RTX_FLAG_STAGE_TIMES), st);
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct Events {
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    hipEvent_t& ev0 = ev.a;
+    hipEvent_t& ev1 = ev.b;
     if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, st)); }
     if (count_work) {
         HIP_TRY(hipMemsetAsync(w.work, 0, 8 * sizeof(unsigned long long), st));
@@ -881,7 +886,6 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         local.ms_total = ms;
         timer.collect();
-        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
         if (count_work) {
             local.branch_visits = w.host_work[0]; local.leaf_visits = w.host_work[1]; local.aabb_tests = w.host_work[2];
             local.triangle_tests = w.host_work[3]; local.sphere_tests = w.host_work[4]; local.hits_accepted = w.host_work[5];

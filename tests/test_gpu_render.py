@@ -398,3 +398,32 @@ def test_full_size_path_depth8_lens_scene_properties(gpu):
         assert torch.equal(fb, both)
         assert st.rays_primary == 2 * W * H and st.rays_secondary > st.rays_primary
         assert torch.isfinite(both).all() and float(both.max()) > 0.1
+
+
+def test_sequence_prefetch_gives_the_same_frames(gpu):
+    """Animated frames with the next frame's scene prepared on a worker thread while the
+    current one renders: same images as preparing every frame in line, and an early stop
+    leaves nothing behind."""
+    from raytracer_amd import sequence
+    s = scenes.animated_scene(copies=1, slices=40, stacks=20)
+    times = [f / 30.0 for f in range(1, 5)]
+    frames = {}
+    for prefetch in (False, True):
+        for k, t, ds, host_s in sequence.device_scenes(s, times, prefetch=prefetch):
+            rd = scenes.render_desc(96, 54, integrator=abi.INTEGRATOR_PATH, n=2, max_depth=4, bias=1e-3, frame=k,
+                                    camera=scenes.orbit_camera(t, radius=30.0, height=6.0))
+            frames[(prefetch, k)], _ = ds.render(rd)
+            assert host_s > 0.0
+    for k in range(len(times)):
+        assert np.array_equal(frames[(False, k)], frames[(True, k)])
+    assert not np.array_equal(frames[(True, 0)], frames[(True, 3)])      # the emissive spheres moved
+    for k, t, ds, _ in sequence.device_scenes(s, times):
+        if k == 1:
+            break
+    # the scene is still usable afterwards
+    desc = s.frame(times[0])
+    with gpu.DeviceScene(desc) as ds:
+        rd = scenes.render_desc(96, 54, integrator=abi.INTEGRATOR_PATH, n=2, max_depth=4, bias=1e-3, frame=0,
+                                camera=scenes.orbit_camera(times[0], radius=30.0, height=6.0))
+        again, _ = ds.render(rd)
+    assert np.array_equal(again, frames[(True, 0)])

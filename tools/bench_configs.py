@@ -118,6 +118,19 @@ def main():
         if args.brief:
             out = {k: out[k] for k in ("config", "refill_lanes", "Mrays_per_s", "ms_per_frame", "stage_ms")}
         print(json.dumps(out), flush=True)
+        if animated:
+            # the same frames through the sequence driver: the host work of frame f+1 (redoAABBs,
+            # KD build, flatten, BVH build, upload) runs on a worker thread while frame f renders
+            from raytracer_amd import sequence
+            ds.close()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k, t, dsk, _ in sequence.device_scenes(scene, [(1 + f) / 30.0 for f in range(frames)], stream=stream):
+                fb.zero_()
+                dsk.render_device(rd_of(1 + k), fb.data_ptr())
+            torch.cuda.synchronize()
+            print(json.dumps({"config": name, "sequence_prefetch_s_per_frame": round((time.perf_counter() - t0) / frames, 3),
+                              "sequential_s_per_frame": round(dt / frames + host_s / frames, 3)}), flush=True)
         ds.close()
         scene.close()
 
