@@ -238,7 +238,6 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
     desc = scene.frame(0.0)
     ds = device.DeviceScene(desc, stream=stream)
     rays = [0]
-    band_rows = max(8, (H // (4 * world)) // 8 * 8)     # four interleaved bands per rank
 
     def one_frame(f):
         cam = scenes.orbit_camera(f / 30.0)
@@ -247,7 +246,8 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
             rd = scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=4, light_n=2, max_depth=3,
                                     bias=1e-2, frame=f, tile=(x0, y0, w, h))
             rays[0] += ds.render_device(rd, out.data_ptr()).rays
-        return rdist.render_frame_bands(render_rect, W, H, dev, band_rows=band_rows,
+        # four interleaved bands of equal height per rank
+        return rdist.render_frame_bands(render_rect, W, H, dev, bands_per_rank=4,
                                         comm_device=None if comm_dev == dev else comm_dev)
 
     def sync():
@@ -271,7 +271,7 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
         dt = mx[0].item()
     ds.close()
     return {"workload": "configs[3]: GGX-parameter mesh, texture + checker floor, SquareLight 2x2 samples, 1080p 16 spp, "
-                        f"whitted; one frame in interleaved {band_rows}-row bands over all ranks",
+                        f"whitted; one frame in {4 * world} interleaved bands of equal height, four per rank",
             "ms_per_frame": round(dt / frames * 1e3, 3), "Mrays_per_s": round(tt[1].item() / dt / 1e6, 1),
             "frames": frames, "n_gpus": world, "scaling": "strong"}
 

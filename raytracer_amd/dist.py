@@ -17,13 +17,22 @@ import torch
 import torch.distributed as dist
 
 
-def band_rects(width, height, world, rank, band_rows=64):
-    """(x0, y0, w, h) of the bands owned by `rank`, top to bottom in frame order."""
-    rects = []
-    for b, y0 in enumerate(range(0, height, band_rows)):
-        if b % world == rank:
-            rects.append((0, y0, width, min(band_rows, height - y0)))
-    return rects
+def band_edges(height, world, band_rows=64, bands_per_rank=None):
+    """Row boundaries of the bands of a frame.  With `bands_per_rank` the frame is cut into
+    world * bands_per_rank bands of (nearly) equal height, so that every rank owns the same
+    number of bands and, within a row, of rows; otherwise bands are `band_rows` rows high."""
+    if bands_per_rank:
+        n = min(height, world * bands_per_rank)
+        return [(b * height) // n for b in range(n + 1)]
+    edges = list(range(0, height, band_rows)) + [height]
+    return edges
+
+
+def band_rects(width, height, world, rank, band_rows=64, bands_per_rank=None):
+    """(x0, y0, w, h) of the bands owned by `rank`, top to bottom in frame order: band b
+    belongs to rank b % world."""
+    edges = band_edges(height, world, band_rows, bands_per_rank)
+    return [(0, edges[b], width, edges[b + 1] - edges[b]) for b in range(len(edges) - 1) if b % world == rank]
 
 
 def frames_for_rank(n_frames, world, rank):
@@ -39,22 +48,25 @@ def _gather_to_rank0(local, world, rank, group=None):
     return out
 
 
-def render_frame_bands(render_rect, width, height, device, band_rows=64, group=None, comm_device=None):
+def render_frame_bands(render_rect, width, height, device, band_rows=64, group=None, comm_device=None,
+                       bands_per_rank=None):
     """Render one frame cooperatively.
 
     render_rect(x0, y0, w, h, out) must accumulate the rectangle's float32 RGB into `out`
     (a [h, w, 3] tensor on `device`, zero-initialised here).  Returns the assembled
     [height, width, 3] frame on rank 0 and None on the other ranks.  `comm_device` is where
     the gather runs when the process group cannot move `device` tensors (gloo with GPU
-    framebuffers); the frame is then returned there.
+    framebuffers); the frame is then returned there.  Bands: see band_edges().
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    n_bands = (height + band_rows - 1) // band_rows
+    edges = band_edges(height, world, band_rows, bands_per_rank)
+    n_bands = len(edges) - 1
     per_rank = (n_bands + world - 1) // world
+    tallest = max(edges[b + 1] - edges[b] for b in range(n_bands))
     # every rank packs its bands into the same padded shape so that one gather moves them
-    packed = torch.zeros((per_rank, band_rows, width, 3), dtype=torch.float32, device=device)
-    mine = band_rects(width, height, world, rank, band_rows)
+    packed = torch.zeros((per_rank, tallest, width, 3), dtype=torch.float32, device=device)
+    mine = band_rects(width, height, world, rank, band_rows, bands_per_rank)
     for k, (x0, y0, w, h) in enumerate(mine):
         render_rect(x0, y0, w, h, packed[k, :h])
     if comm_device is not None and torch.device(comm_device) != packed.device:
@@ -64,7 +76,7 @@ def render_frame_bands(render_rect, width, height, device, band_rows=64, group=N
         return None
     frame = torch.empty((height, width, 3), dtype=torch.float32, device=packed.device)
     for r in range(world):
-        for k, (x0, y0, w, h) in enumerate(band_rects(width, height, world, r, band_rows)):
+        for k, (x0, y0, w, h) in enumerate(band_rects(width, height, world, r, band_rows, bands_per_rank)):
             frame[y0:y0 + h] = parts[r][k, :h]
     return frame
 

@@ -47,11 +47,12 @@ def _worker(rank, world, port, mode, out_path):
     from raytracer_amd import dist as rdist
     from oracle import binding as orc
     scene, desc, cam = _scene_and_desc()
-    if mode == "bands":
+    if mode in ("bands", "even-bands"):
         def render_rect(x0, y0, w, h, out):
             img, _, _, _ = orc.render(desc, _rd(cam, tile=(x0, y0, w, h)), threads=2)
             out += torch.from_numpy(img)
-        frame = rdist.render_frame_bands(render_rect, W, H, torch.device("cpu"), band_rows=16)
+        frame = rdist.render_frame_bands(render_rect, W, H, torch.device("cpu"), band_rows=16,
+                                         bands_per_rank=3 if mode == "even-bands" else None)
         if rank == 0:
             np.save(out_path, frame.numpy())
     else:
@@ -65,14 +66,14 @@ def _worker(rank, world, port, mode, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["bands", "frames"])
+@pytest.mark.parametrize("mode", ["bands", "even-bands", "frames"])
 def test_two_ranks_reproduce_the_single_process_image(tmp_path, mode):
     out_path = str(tmp_path / "out.npy")
     mp.spawn(_worker, args=(2, _free_port(), mode, out_path), nprocs=2, join=True)
     got = np.load(out_path)
     from oracle import binding as orc
     scene, desc, cam = _scene_and_desc()
-    if mode == "bands":
+    if mode in ("bands", "even-bands"):
         want, _, _, _ = orc.render(desc, _rd(cam))
         assert np.array_equal(got, want)
     else:
@@ -91,3 +92,15 @@ def test_band_partition_covers_the_frame_once():
                 seen[y0:y0 + h] += 1
         assert (seen == 1).all()
     assert rdist.frames_for_rank(10, 4, 1) == [1, 5, 9]
+    # equal-share bands: every rank owns the same number of bands and, within a row, of rows
+    for world in (1, 2, 3, 4, 8):
+        seen = np.zeros(1080, int)
+        rows = []
+        for r in range(world):
+            rects = rdist.band_rects(1920, 1080, world, r, bands_per_rank=4)
+            assert len(rects) == 4
+            rows.append(sum(h for (_, _, _, h) in rects))
+            for (x0, y0, w, h) in rects:
+                seen[y0:y0 + h] += 1
+        assert (seen == 1).all() and max(rows) - min(rows) <= 4
+    assert len(rdist.band_rects(8, 3, 2, 0, bands_per_rank=4)) + len(rdist.band_rects(8, 3, 2, 1, bands_per_rank=4)) == 3
