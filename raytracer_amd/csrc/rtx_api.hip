@@ -816,9 +816,14 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                     const uint64_t gather_max = p.gather_traced ? (uint64_t)count * p.gather_samples * sc->d.n_lights : 0;
                     if (gather_max > w.gather_capacity) return fail(RTX_ERR_LIMIT, "gather queue overflow");
                     timer.begin();
-                    hipLaunchKernelGGL(k_shade_whitted_a, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                       w.counts + 1, w.shadow_index, w.shadow_stride, w.gq, w.counts + 2, w.gather_index,
-                                       w.sample);
+                    if (p.gather_samples)
+                        hipLaunchKernelGGL(k_shade_whitted_a<true>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
+                                           w.counts + 1, w.shadow_index, w.shadow_stride, w.gq, w.counts + 2, w.gather_index,
+                                           w.sample);
+                    else
+                        hipLaunchKernelGGL(k_shade_whitted_a<false>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
+                                           w.counts + 1, w.shadow_index, w.shadow_stride, w.gq, w.counts + 2, w.gather_index,
+                                           w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                     // the shadow queue's length stays on the device: the launch is sized for the
@@ -844,8 +849,12 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                         local.traverse_launches++;
                     }
                     timer.begin();
-                    hipLaunchKernelGGL(k_shade_whitted_b, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                       w.shadow_index, w.shadow_stride, w.gq, w.gather_index, nq, w.counts + 0, w.sample);
+                    if (p.gather_samples)
+                        hipLaunchKernelGGL(k_shade_whitted_b<true>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
+                                           w.shadow_index, w.shadow_stride, w.gq, w.gather_index, nq, w.counts + 0, w.sample);
+                    else
+                        hipLaunchKernelGGL(k_shade_whitted_b<false>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
+                                           w.shadow_index, w.shadow_stride, w.gq, w.gather_index, nq, w.counts + 0, w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                 }

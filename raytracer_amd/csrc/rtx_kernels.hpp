@@ -1168,7 +1168,9 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
 // Hit rays get shadow_per_hit shadow-queue entries, shadow_stride[i] apart from shadow_base[i] on,
 // and with GLOBAL_LIGHTING n_lights * gather_samples gather-queue entries, the same stride apart
 // from gather_base[i] on.  Random numbers are drawn in the reference's order: per light first
-// the SquareLight samples, then the gather directions.
+// the SquareLight samples, then the gather directions.  GATHER = false compiles the gather out
+// (it costs registers, hence resident waves, even when it does not run).
+template <bool GATHER>
 __global__ void __launch_bounds__(kBlock)
 k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, uint32_t* shadow_count,
                   uint32_t* shadow_base, uint32_t* shadow_stride, GatherQueue gq, uint32_t* gather_count,
@@ -1185,14 +1187,17 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
         }
     }
     const bool lit = !(p.d.flags & RTX_FLAG_NO_LIGHTING) && s.n_lights > 0;
-    const uint32_t gather_per_hit = (lit && p.gather_traced) ? s.n_lights * p.gather_samples : 0u;
-    bool emit = hit && lit && (p.shadow_per_hit > 0 || p.gather_samples > 0);
+    const uint32_t gather_samples = GATHER ? p.gather_samples : 0u;
+    const uint32_t gather_per_hit = (GATHER && lit && p.gather_traced) ? s.n_lights * gather_samples : 0u;
+    bool emit = hit && lit && (p.shadow_per_hit > 0 || gather_samples > 0);
     __shared__ uint32_t reserve_lds[kBlock / 64 + 2];
     // the workgroup's entries are laid out sample-major: entry (hit j of the workgroup, sample m)
     // sits at block_base + m * block_hits + j, so that for one m the lanes write neighbours
     uint32_t block_hits = 0, block_base = 0, rank = 0, gblock_base = 0;
     block_reserve(emit, shadow_count, p.shadow_per_hit, reserve_lds, &block_hits, &block_base, &rank);
-    if (gather_per_hit) block_reserve(emit, gather_count, gather_per_hit, reserve_lds, nullptr, &gblock_base);
+    if constexpr (GATHER) {
+        if (gather_per_hit) block_reserve(emit, gather_count, gather_per_hit, reserve_lds, nullptr, &gblock_base);
+    }
     const uint32_t base = block_base + rank;
     if (i < n) {
         shadow_base[i] = base; shadow_stride[i] = block_hits;
@@ -1219,15 +1224,17 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
                 sq.dx[k] = lr.d.x; sq.dy[k] = lr.d.y; sq.dz[k] = lr.d.z;
                 sq.limit[k] = light_distance(l, lr);
             }
-            if (gather_per_hit) {
-                for (uint32_t gm = 0; gm < p.gather_samples; ++gm, g += block_hits) {
-                    // Ray lightRay(minRayResult.position, randomHemisphericalVector(normal)) (:503-505)
-                    Ray gr = make_ray(h.position, random_hemispherical_desktop(h.normal, rng));
-                    gq.ox[g] = gr.o.x; gq.oy[g] = gr.o.y; gq.oz[g] = gr.o.z;
-                    gq.dx[g] = gr.d.x; gq.dy[g] = gr.d.y; gq.dz[g] = gr.d.z;
+            if constexpr (GATHER) {
+                if (gather_per_hit) {
+                    for (uint32_t gm = 0; gm < gather_samples; ++gm, g += block_hits) {
+                        // Ray lightRay(minRayResult.position, randomHemisphericalVector(normal)) (:503-505)
+                        Ray gr = make_ray(h.position, random_hemispherical_desktop(h.normal, rng));
+                        gq.ox[g] = gr.o.x; gq.oy[g] = gr.o.y; gq.oz[g] = gr.o.z;
+                        gq.dx[g] = gr.d.x; gq.dy[g] = gr.d.y; gq.dz[g] = gr.d.z;
+                    }
+                } else {
+                    rng.counter += 2u * gather_samples;     // directions whose nested call ends at the layer limit
                 }
-            } else {
-                rng.counter += 2u * p.gather_samples;   // directions whose nested call ends at the layer limit
             }
         }
         q.counter[i] = rng.counter;       // the refraction child continues this stream
@@ -1235,6 +1242,7 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
 }
 
 // second half: direct lighting from the shadow results, the gather's sum, blend, spawn children
+template <bool GATHER>
 __global__ void __launch_bounds__(kBlock)
 k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, const uint32_t* shadow_base,
                   const uint32_t* shadow_stride, GatherQueue gq, const uint32_t* gather_base, RayQueue next,
@@ -1261,7 +1269,7 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
             d3 direct = mk(0, 0, 0), global = mk(0, 0, 0);
             uint32_t k = shadow_base[i];
             const uint32_t stride = shadow_stride[i];
-            uint32_t g = (p.gather_samples && p.gather_traced) ? gather_base[i] : 0u;
+            uint32_t g = (GATHER && p.gather_samples && p.gather_traced) ? gather_base[i] : 0u;
             for (uint32_t li = 0; li < s.n_lights; ++li) {
                 const rtx_light& l = s.lights[li];
                 uint32_t samples = l.multisample ? p.d.light_multisample_n * p.d.light_multisample_n : 1u;
@@ -1276,7 +1284,7 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
                     }
                 }
                 direct = direct / (double)samples;          // inside the light loop (:498)
-                if (p.gather_samples) {                     // GLOBAL_LIGHTING (:499-524)
+                if (GATHER && p.gather_samples) {           // GLOBAL_LIGHTING (:499-524)
                     for (uint32_t gm = 0; gm < p.gather_samples; ++gm, g += stride) {
                         int32_t gp = p.gather_traced ? gq.hit_prim[g] : -1;
                         if (gp >= 0) {
