@@ -210,3 +210,80 @@ def test_bvh_walk_falls_back_on_ties_only(gpu):
                 if name == "bvh":
                     assert (st.fallback_rays > 0) == expect, st.fallback_rays
         assert np.array_equal(imgs["bvh"], imgs["ref"])
+
+
+def _degenerate_scene(offset):
+    """Geometry chosen to sit on KD cell faces and split planes and to stress the culls'
+    margins: axis-aligned quads on integer planes (their boxes are flat and coincide with
+    split values), needle and zero-area triangles, shapes listed twice, a sphere touching
+    a wall -- everything translated by `offset` so that coordinates are large compared with
+    the features."""
+    from raytracer_amd import host
+    rng = np.random.default_rng(21)
+    scene = host.HostScene()
+    m = scene.material("PlainWhiteTees")
+    tris = []
+    for axis in range(3):
+        for plane in (-4.0, -1.0, 0.0, 2.0, 4.0):
+            u, v = [a for a in range(3) if a != axis]
+            for (u0, v0) in ((-4.0, -4.0), (0.0, -4.0), (-4.0, 0.0), (0.0, 0.0)):
+                q = np.zeros((4, 3))
+                q[:, axis] = plane
+                q[:, u] = [u0, u0 + 4.0, u0 + 4.0, u0]
+                q[:, v] = [v0, v0, v0 + 4.0, v0 + 4.0]
+                tris += [q[[0, 1, 2]], q[[0, 2, 3]], q[[2, 1, 0]], q[[3, 2, 0]]]     # both windings
+    c = rng.uniform(-4, 4, size=(150, 1, 3))
+    needle = c + np.concatenate([np.zeros((150, 1, 3)), rng.normal(scale=1.0, size=(150, 1, 3)),
+                                 rng.normal(scale=1e-9, size=(150, 1, 3))], axis=1)
+    needle[:, 2] += needle[:, 1] - c[:, 0]                      # third vertex 1e-9 off the second
+    tris += list(needle)
+    zero = np.repeat(rng.uniform(-4, 4, size=(30, 1, 3)), 3, axis=1)
+    tris += list(zero)
+    small = rng.uniform(-4, 4, size=(300, 1, 3)) + rng.normal(scale=0.3, size=(300, 3, 3))
+    tris += list(small) + list(small[:40])                      # forty shapes present twice
+    pos = np.array(tris) + np.asarray(offset)
+    n = len(pos)
+    nrm = np.tile([0.0, 1.0, 0.0], (n, 3, 1))
+    uv = np.tile([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]], (n, 1, 1))
+    scene.triangles(pos, nrm, uv, m)
+    scene.sphere(tuple(np.asarray(offset) + [1.0, 1.0, 3.0]), 1.0, m)      # touches the plane z = 4 and x = 2
+    return scene
+
+
+@pytest.mark.parametrize("offset", [(0.0, 0.0, 0.0), (5000.0, -3000.0, 7000.0)], ids=["origin", "far"])
+@pytest.mark.parametrize("walk", ["bvh", "kd_culled"])
+def test_degenerate_geometry_walks_match_reference(gpu, walk, offset):
+    """Flat boxes on split planes, needles, zero-area triangles, duplicates, large coordinates:
+    both render-path walks must still report the reference-order walk's hit bit for bit, for
+    random rays, rays lying in the quads' planes, rays starting on the quads, nearly
+    axis-parallel rays and exactly axis-parallel ones."""
+    scene = _degenerate_scene(offset)
+    desc = scene.frame(0.0)
+    rng = np.random.default_rng(22)
+    off = np.asarray(offset)
+    o1, d1 = _random_rays(rng, 30000, box=6.0)
+    # origins on the integer planes, directions inside those planes (grazing) or leaving them
+    o2 = rng.uniform(-4, 4, size=(9000, 3))
+    ax = rng.integers(0, 3, 9000)
+    o2[np.arange(9000), ax] = rng.choice([-4.0, -1.0, 0.0, 2.0, 4.0], 9000)
+    d2 = rng.normal(size=(9000, 3))
+    d2[np.arange(3000), ax[:3000]] = 0.0                        # in-plane
+    # nearly axis-parallel: one dominant component, the others ~1e-12 .. 1e-17
+    d3_ = rng.normal(size=(6000, 3)) * 10.0 ** rng.uniform(-17, -12, size=(6000, 1))
+    d3_[np.arange(6000), rng.integers(0, 3, 6000)] = rng.choice([-1.0, 1.0], 6000)
+    o3 = rng.uniform(-5, 5, size=(6000, 3))
+    d4 = np.eye(3)[rng.integers(0, 3, 2000)] * rng.choice([-1.0, 1.0], size=(2000, 1))
+    o4 = np.round(rng.uniform(-5, 5, size=(2000, 3)))           # exactly on the integer planes
+    oo = np.vstack([o1, o2, o3, o4]) + off
+    dd = np.vstack([d1, d2, d3_, d4])
+    flags = abi.FLAG_RENDER_WALK | (abi.FLAG_KD_CULLED if walk == "kd_culled" else 0)
+    with gpu.DeviceScene(desc) as ds:
+        got = ds.trace_closest(oo, dd, flags=flags)
+        ref = ds.trace_closest(oo, dd)
+    want = orc.trace_closest(desc, oo, dd)
+    for key in ("prim", "depth", "position", "normal", "bary"):
+        for name, res in (("reference-order", ref), (walk, got)):
+            g, w = res[key], want[key]
+            same = (g == w) | ((g != g) & (w != w)) if g.dtype.kind == "f" else g == w
+            assert same.all(), f"{name} {key}: {np.count_nonzero(~same)} of {same.size} differ"
+    assert (want["prim"] >= 0).mean() > 0.3
