@@ -710,6 +710,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
             shadow_per_hit += multisample ? rd->light_multisample_n * rd->light_multisample_n : 1u;
     }
     p.shadow_per_hit = shadow_per_hit;
+    p.atomic_samples = (whitted && (rd->flags & RTX_FLAG_WHITTED_REFLECT)) ? 1u : 0u;
     // GLOBAL_LIGHTING: globalSamples per light at a level (Raytracer-Noah-Desktop.cpp:500); MAXBOUNCES = 0
     // makes the reference's factor NaN, taken as no samples
     const bool gather = whitted && (rd->flags & RTX_FLAG_GLOBAL_LIGHTING) && !(rd->flags & RTX_FLAG_NO_LIGHTING) &&

@@ -62,6 +62,7 @@ struct RenderParams {
     uint32_t gather_samples;    // globalSamples per light (:500); 0 = off
     uint32_t gather_traced;     // 1 when layer+1 <= MAXBOUNCES, i.e. the nested call shoots its ray
     uint32_t gather_cap;
+    uint32_t atomic_samples;    // 1: several rays of one launch may add to the same sample slot
 };
 
 // ---- traversal core -------------------------------------------------------------------------
@@ -995,13 +996,21 @@ k_generate(RenderParams p, RayQueue q)
     push_ray(q, slot, make_ray(eye, v), mk(1.0, 1.0, 1.0), 1.0, slot, 0u, 0u, 0u);
 }
 
-RTX_DEV void sample_add(double* sample, uint32_t slot, d3 v)
+RTX_DEV void sample_add(const RenderParams& p, double* sample, uint32_t slot, d3 v)
 {
-    // a sample can receive terms from several rays of one launch only with the mirror
-    // extension of the Whitted integrator, hence atomics
-    unsafeAtomicAdd(sample + 3 * (size_t)slot + 0, v.x);
-    unsafeAtomicAdd(sample + 3 * (size_t)slot + 1, v.y);
-    unsafeAtomicAdd(sample + 3 * (size_t)slot + 2, v.z);
+    // A zero term (black clear colour, an opaque surface's transparent part) leaves the sum as
+    // it is and is not sent at all.  Every sample slot has one live ray per launch, so a plain
+    // read-modify-write is enough -- except with the mirror extension of the Whitted
+    // integrator, whose two children per hit can reach a slot in the same launch: atomics then.
+    if (v.x == 0.0 && v.y == 0.0 && v.z == 0.0) return;
+    double* at = sample + 3 * (size_t)slot;
+    if (p.atomic_samples) {
+        unsafeAtomicAdd(at + 0, v.x);
+        unsafeAtomicAdd(at + 1, v.y);
+        unsafeAtomicAdd(at + 2, v.z);
+    } else {
+        at[0] += v.x; at[1] += v.y; at[2] += v.z;
+    }
 }
 
 RTX_DEV Rng ray_rng(const RenderParams& p, const RayQueue& q, uint32_t i, uint32_t slot)
@@ -1093,7 +1102,7 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
         d3 clear = ld3(p.d.clear_color);
         int32_t prim = q.hit_prim[i];
         if (prim < 0) {
-            sample_add(sample, slot, w * (clear * 0.1));
+            sample_add(p, sample, slot, w * (clear * 0.1));
         } else {
             d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
             d3 inv_dir = -d;
@@ -1101,7 +1110,7 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
             prim_full(s, (uint32_t)prim, o, d, h);
             const rtx_material& m = s.materials[s.prim_material[prim]];
             if (p.d.flags & RTX_FLAG_BASIC) {
-                sample_add(sample, slot, w * material_color(s, m, h.u, h.v));
+                sample_add(p, sample, slot, w * material_color(s, m, h.u, h.v));
             } else {
                 double trans = sample_scalar(s, m.transparency_fn, m.transparency, h.u, h.v);
                 double smooth = sample_scalar(s, m.smoothness_fn, m.smoothness, h.u, h.v);
@@ -1113,7 +1122,7 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
                 bool entering = is_entering(h.normal, inv_dir);
                 d3 emission = ld3(m.emission);
                 if (!(emission.x == 0.0 && emission.y == 0.0 && emission.z == 0.0)) {
-                    sample_add(sample, slot, w * emission);
+                    sample_add(p, sample, slot, w * emission);
                 } else {
                     double ni = sample_scalar(s, m.ni_fn, m.ni, h.u, h.v);
                     d3 dir, pos;
@@ -1153,7 +1162,7 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
                         cw = w * (spec + (kD * diffuse));
                     }
                     cior = ni; cbranch = rng.branch; ccounter = rng.counter;
-                    if (layer + 1 > p.d.max_depth) sample_add(sample, slot, cw * (clear * 0.1));   // :220-222
+                    if (layer + 1 > p.d.max_depth) sample_add(p, sample, slot, cw * (clear * 0.1));   // :220-222
                     else spawn = true;
                 }
             }
@@ -1181,7 +1190,7 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
     if (i < n) {
         int32_t prim = q.hit_prim[i];
         if (prim < 0) {
-            sample_add(sample, q.slot[i], mk(q.wx[i], q.wy[i], q.wz[i]) * ld3(p.d.clear_color));
+            sample_add(p, sample, q.slot[i], mk(q.wx[i], q.wy[i], q.wz[i]) * ld3(p.d.clear_color));
         } else {
             hit = true;
         }
@@ -1317,10 +1326,10 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
             d3 pos = h.position + ((h.normal * (entering ? -1.0 : 1.0)) * p.d.bias);
             child_t = make_ray(pos, dir);
             wt = w * wtrans;
-            if (layer + 1 > p.d.max_depth) sample_add(sample, slot, wt * clear);    // :456-460
+            if (layer + 1 > p.d.max_depth) sample_add(p, sample, slot, wt * clear);    // :456-460
             else spawn_t = true;
         } else {
-            sample_add(sample, slot, w * (clear * wtrans));  // transparentRayResult stays clearColor (:532)
+            sample_add(p, sample, slot, w * (clear * wtrans));  // transparentRayResult stays clearColor (:532)
         }
         double wl = 1.0 - trans;
         if (p.d.flags & RTX_FLAG_WHITTED_REFLECT) {
@@ -1328,12 +1337,12 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
             if (smooth != 0.0) {
                 child_r = make_ray(h.position + (h.normal * p.d.bias), mirror_direction(d, h.normal));
                 wr = w * (smooth * wl);
-                if (layer + 1 > p.d.max_depth) sample_add(sample, slot, wr * clear);
+                if (layer + 1 > p.d.max_depth) sample_add(p, sample, slot, wr * clear);
                 else spawn_r = true;
                 wl = wl * (1.0 - smooth);
             }
         }
-        sample_add(sample, slot, w * (local * wl));
+        sample_add(p, sample, slot, w * (local * wl));
     }
     __shared__ uint32_t reserve_lds[kBlock / 64 + 2];
     uint32_t jt = block_reserve(spawn_t, next_count, 1, reserve_lds);
