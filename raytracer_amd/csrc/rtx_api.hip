@@ -75,16 +75,14 @@ struct Workspace {
     RayQueue q[2];
     ShadowQueue sq;
     GatherQueue gq;
-    uint32_t* gather_index = nullptr;       // per ray: first gather entry
     uint32_t* cand = nullptr;               // per traced ray: candidate left by k_trace_refill for k_verify
     size_t cand_capacity = 0;
-    uint32_t* shadow_index = nullptr;       // per ray: first shadow entry
-    uint32_t* shadow_stride = nullptr;      // per ray: distance between its entries
+    uint32_t* hit_index = nullptr;          // per ray: compact index among the level's hits
     uint32_t* perm = nullptr;               // shading order (material sort)
     uint32_t* bins = nullptr;               // 2 * kBins: histogram, next free place per bin
     double* sample = nullptr;               // 3 per slot
-    uint32_t* counts = nullptr;             // [0] next queue, [1] shadow queue, [2] gather queue
-    unsigned long long* work = nullptr;     // 8 work counters + the shadow and gather rays of single-level frames
+    uint32_t* counts = nullptr;             // [0] next queue, [1] hits of the level being shaded
+    unsigned long long* work = nullptr;     // 8 work counters, [8] hits of single-level frames, [10..11] SIMD efficiency
     uint32_t* host_counts = nullptr;        // pinned
     unsigned long long* host_work = nullptr;
     ~Workspace()
@@ -113,7 +111,7 @@ size_t queue_bytes(size_t cap)
 {
     auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
     size_t per_queue = 10 * al(cap * 8) + 4 * al(cap * 4) + al(cap * 4) + al(cap * 8);
-    return 2 * per_queue + 4 * al(cap * 4) + al(cap * 3 * 8);
+    return 2 * per_queue + 2 * al(cap * 4) + al(cap * 3 * 8) + 6 * al(cap * 8);
 }
 
 }  // namespace
@@ -160,9 +158,10 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap, size_t gather
             q.branch = carve<uint32_t>(p, cap); q.counter = carve<uint32_t>(p, cap);
             q.hit_prim = carve<int32_t>(p, cap); q.hit_depth = carve<double>(p, cap);
         }
-        w.shadow_index = carve<uint32_t>(p, cap);
-        w.shadow_stride = carve<uint32_t>(p, cap);
-        w.gather_index = carve<uint32_t>(p, cap);
+        w.hit_index = carve<uint32_t>(p, cap);
+        // origins of the light rays, one per hit
+        w.sq.ox = carve<double>(p, cap); w.sq.oy = carve<double>(p, cap); w.sq.oz = carve<double>(p, cap);
+        w.gq.ox = carve<double>(p, cap); w.gq.oy = carve<double>(p, cap); w.gq.oz = carve<double>(p, cap);
         w.perm = carve<uint32_t>(p, cap);
         w.sample = carve<double>(p, cap * 3);
         w.capacity = cap;
@@ -170,10 +169,9 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap, size_t gather
     if (shadow_cap > w.shadow_capacity) {
         if (w.shadow_base_mem) { HIP_TRY(hipFree(w.shadow_base_mem)); w.shadow_base_mem = nullptr; w.shadow_capacity = 0; }
         auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
-        HIP_TRY(hipMalloc(&w.shadow_base_mem, 8 * al(shadow_cap * 8)));
+        HIP_TRY(hipMalloc(&w.shadow_base_mem, 5 * al(shadow_cap * 8)));
         char* p = w.shadow_base_mem;
         ShadowQueue& s = w.sq;
-        s.ox = carve<double>(p, shadow_cap); s.oy = carve<double>(p, shadow_cap); s.oz = carve<double>(p, shadow_cap);
         s.dx = carve<double>(p, shadow_cap); s.dy = carve<double>(p, shadow_cap); s.dz = carve<double>(p, shadow_cap);
         s.limit = carve<double>(p, shadow_cap);
         s.hit_depth = carve<double>(p, shadow_cap);
@@ -182,10 +180,9 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap, size_t gather
     if (gather_cap > w.gather_capacity) {
         if (w.gather_base_mem) { HIP_TRY(hipFree(w.gather_base_mem)); w.gather_base_mem = nullptr; w.gather_capacity = 0; }
         auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
-        HIP_TRY(hipMalloc(&w.gather_base_mem, 7 * al(gather_cap * 8) + al(gather_cap * 4)));
+        HIP_TRY(hipMalloc(&w.gather_base_mem, 4 * al(gather_cap * 8) + al(gather_cap * 4)));
         char* p = w.gather_base_mem;
         GatherQueue& g = w.gq;
-        g.ox = carve<double>(p, gather_cap); g.oy = carve<double>(p, gather_cap); g.oz = carve<double>(p, gather_cap);
         g.dx = carve<double>(p, gather_cap); g.dy = carve<double>(p, gather_cap); g.dz = carve<double>(p, gather_cap);
         g.hit_depth = carve<double>(p, gather_cap);
         g.hit_prim = carve<int32_t>(p, gather_cap);
@@ -631,10 +628,12 @@ int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* directi
     return RTX_OK;
 }
 
-// limit == nullptr: closest hit; otherwise any hit with depth <= limit[i] (shadow rays)
+// limit == nullptr: closest hit; otherwise any hit with depth <= limit[i] (shadow rays).
+// seg == 0: the first min(n, *n_device) rays of a flat queue; seg != 0: a light-ray queue of
+// n = samples * seg entries, of which *n_device hits x samples are in use (see ray_place).
 static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const double* oz, const double* dx,
                         const double* dy, const double* dz, const double* limit, uint32_t n, const uint32_t* n_device,
-                        uint32_t flags, int32_t* hit_prim, double* hit_depth, bool count)
+                        uint32_t seg, uint32_t flags, int32_t* hit_prim, double* hit_depth, bool count)
 {
     uint32_t linear = (flags & RTX_FLAG_LINEAR_SCAN) ? 1u : 0u;
     int mode;
@@ -643,31 +642,35 @@ static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const
     else mode = limit ? 4 : 3;
     Counters g;
     g.c = count ? sc->ws.work : nullptr;
-    dim3 grid = trace_grid_for(n), block(kTraceBlock);
+    // threads to launch: light-ray queues are enumerated in whole tiles of hits (ray_total)
+    uint64_t threads = n;
+    if (seg) threads = ((uint64_t)seg + kRayTile - 1) / kRayTile * kRayTile * (n / seg);
+    if (threads > 0xffffffffull) return fail(RTX_ERR_LIMIT, "more than 2^32 light rays in one launch: lower RTX_MAX_PATHS");
+    dim3 grid = trace_grid_for(threads), block(kTraceBlock);
     if (mode >= 3 && (flags & RTX_FLAG_REFILL_LANES) && n <= sc->ws.cand_capacity) {
         // lanes refilled from the wave's own range of the queue; ranges shrink for small launches
         // so that every resident wave slot gets several
         const int anyhit = limit ? 1 : 0;
         const uint64_t slots = (uint64_t)sc->compute_units * 16u;
-        const uint32_t rays_per_wave = (uint32_t)std::min<uint64_t>(sc->refill_range, std::max<uint64_t>(64, ((uint64_t)n / (slots * 4)) / 64 * 64));
-        dim3 pgrid((unsigned)(((uint64_t)n + rays_per_wave - 1) / rays_per_wave));
+        const uint32_t rays_per_wave = (uint32_t)std::min<uint64_t>(sc->refill_range, std::max<uint64_t>(64, (threads / (slots * 4)) / 64 * 64));
+        dim3 pgrid((unsigned)((threads + rays_per_wave - 1) / rays_per_wave));
 #define RTX_LAUNCH_REFILL(COUNT, ANYHIT)                                                                              \
     hipLaunchKernelGGL((k_trace_refill<COUNT, ANYHIT>), pgrid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
-                       n_device, sc->refill_at, rays_per_wave, hit_prim, hit_depth, sc->ws.cand, g)
+                       n_device, seg, sc->refill_at, rays_per_wave, hit_prim, hit_depth, sc->ws.cand, g)
         if (count) { if (anyhit) RTX_LAUNCH_REFILL(true, true); else RTX_LAUNCH_REFILL(true, false); }
         else { if (anyhit) RTX_LAUNCH_REFILL(false, true); else RTX_LAUNCH_REFILL(false, false); }
 #undef RTX_LAUNCH_REFILL
         HIP_TRY(hipGetLastError());
         if (count) hipLaunchKernelGGL(k_verify<true>, grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, n, n_device,
-                                      sc->ws.cand, hit_prim, hit_depth, g);
+                                      seg, sc->ws.cand, hit_prim, hit_depth, g);
         else hipLaunchKernelGGL(k_verify<false>, grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, n, n_device,
-                                sc->ws.cand, hit_prim, hit_depth, g);
+                                seg, sc->ws.cand, hit_prim, hit_depth, g);
         HIP_TRY(hipGetLastError());
         return RTX_OK;
     }
 #define RTX_LAUNCH_TRACE(COUNT, MODE)                                                                                  \
     hipLaunchKernelGGL((k_trace_pool<COUNT, MODE>), grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
-                       n_device, linear, hit_prim, hit_depth, g)
+                       n_device, seg, linear, hit_prim, hit_depth, g)
 #define RTX_LAUNCH_MODES(COUNT)                                                                   \
     switch (mode) {                                                                               \
     case 0: RTX_LAUNCH_TRACE(COUNT, 0); break;                                                    \
@@ -751,8 +754,6 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     Workspace& w = sc->ws;
     hipStream_t st = sc->stream;
     p.queue_cap = (uint32_t)std::min<size_t>(w.capacity, 0xffffffffu);
-    p.shadow_cap = (uint32_t)std::min<size_t>(w.shadow_capacity, 0xffffffffu);
-    p.gather_cap = (uint32_t)std::min<size_t>(w.gather_capacity, 0xffffffffu);
 
     rtx_stats local;
     std::memset(&local, 0, sizeof local);
@@ -769,7 +770,8 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         HIP_TRY(hipMemsetAsync(w.work + 10, 0, 2 * sizeof(unsigned long long), st));
     }
     const bool single_level = whitted && !sc->may_refract && !(rd->flags & RTX_FLAG_WHITTED_REFLECT);
-    if (single_level) HIP_TRY(hipMemsetAsync(w.work + 8, 0, 2 * sizeof(unsigned long long), st));
+    if (single_level) HIP_TRY(hipMemsetAsync(w.work + 8, 0, sizeof(unsigned long long), st));
+    uint32_t single_shadow_per_hit = 0, single_gather_per_hit = 0;
 
     for (uint32_t pass = rd->first_pass; pass < rd->first_pass + rd->passes; ++pass) {
         p.pass = pass;
@@ -786,6 +788,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
             uint32_t count = (uint32_t)slots;        // one camera ray per sample slot
             int cur = 0;
             uint32_t level = 0;
+            uint32_t level_shadow_per_hit = 0, level_gather_per_hit = 0;    // light rays per lit hit at the level just shaded
             while (count > 0) {
                 if (count > queue_cap) return fail(RTX_ERR_LIMIT, "ray queue overflow (%u > %zu)", count, queue_cap);
                 RayQueue& q = w.q[cur];
@@ -793,12 +796,12 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 local.max_queue = std::max(local.max_queue, count);
                 if (level == 0) local.rays_primary += count; else local.rays_secondary += count;
                 timer.begin();
-                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, count, nullptr, rd->flags, q.hit_prim, q.hit_depth,
+                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, count, nullptr, 0, rd->flags, q.hit_prim, q.hit_depth,
                                   count_work);
                 if (rc != RTX_OK) return rc;
                 timer.end(&local.ms_traverse);
                 local.traverse_launches++;
-                HIP_TRY(hipMemsetAsync(w.counts, 0, 3 * sizeof(uint32_t), st));
+                HIP_TRY(hipMemsetAsync(w.counts, 0, 2 * sizeof(uint32_t), st));
                 if (!whitted) {
                     timer.begin();
                     const uint32_t* perm = nullptr;
@@ -814,27 +817,27 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 } else {
                     p.gather_samples = gather_samples_at(level);
                     p.gather_traced = level + 1 <= rd->max_depth ? 1u : 0u;
-                    const uint64_t gather_max = p.gather_traced ? (uint64_t)count * p.gather_samples * sc->d.n_lights : 0;
+                    p.seg = count;
+                    const uint32_t gather_per_hit = p.gather_traced ? p.gather_samples * sc->d.n_lights : 0u;
+                    const uint64_t gather_max = (uint64_t)count * gather_per_hit;
+                    const uint64_t shadow_max = (uint64_t)count * shadow_per_hit;
                     if (gather_max > w.gather_capacity) return fail(RTX_ERR_LIMIT, "gather queue overflow");
+                    if (shadow_max > w.shadow_capacity) return fail(RTX_ERR_LIMIT, "shadow queue overflow");
                     timer.begin();
                     if (p.gather_samples)
                         hipLaunchKernelGGL(k_shade_whitted_a<true>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                           w.counts + 1, w.shadow_index, w.shadow_stride, w.gq, w.counts + 2, w.gather_index,
-                                           w.sample);
+                                           w.counts + 1, w.hit_index, w.gq, w.sample);
                     else
                         hipLaunchKernelGGL(k_shade_whitted_a<false>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                           w.counts + 1, w.shadow_index, w.shadow_stride, w.gq, w.counts + 2, w.gather_index,
-                                           w.sample);
+                                           w.counts + 1, w.hit_index, w.gq, w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
-                    // the shadow queue's length stays on the device: the launch is sized for the
-                    // most it can be and reads the real length itself
-                    uint64_t shadow_max = (uint64_t)count * shadow_per_hit;
-                    if (shadow_max > w.shadow_capacity) return fail(RTX_ERR_LIMIT, "shadow queue overflow");
+                    // the number of hits stays on the device: the launches are sized for the most
+                    // there can be and read the real number themselves
                     if (shadow_max > 0) {
                         timer.begin();
                         rc = launch_trace(sc, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, w.sq.limit, (uint32_t)shadow_max,
-                                          w.counts + 1, rd->flags, nullptr, w.sq.hit_depth, count_work);
+                                          w.counts + 1, count, rd->flags, nullptr, w.sq.hit_depth, count_work);
                         if (rc != RTX_OK) return rc;
                         timer.end(&local.ms_shadow);
                         local.traverse_launches++;
@@ -844,7 +847,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                         // closest-hit query each (their colour is discarded, :509-510)
                         timer.begin();
                         rc = launch_trace(sc, w.gq.ox, w.gq.oy, w.gq.oz, w.gq.dx, w.gq.dy, w.gq.dz, nullptr, (uint32_t)gather_max,
-                                          w.counts + 2, rd->flags, w.gq.hit_prim, w.gq.hit_depth, count_work);
+                                          w.counts + 1, count, rd->flags, w.gq.hit_prim, w.gq.hit_depth, count_work);
                         if (rc != RTX_OK) return rc;
                         timer.end(&local.ms_traverse);
                         local.traverse_launches++;
@@ -852,28 +855,31 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                     timer.begin();
                     if (p.gather_samples)
                         hipLaunchKernelGGL(k_shade_whitted_b<true>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                           w.shadow_index, w.shadow_stride, w.gq, w.gather_index, nq, w.counts + 0, w.sample);
+                                           w.hit_index, w.gq, nq, w.counts + 0, w.sample);
                     else
                         hipLaunchKernelGGL(k_shade_whitted_b<false>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                           w.shadow_index, w.shadow_stride, w.gq, w.gather_index, nq, w.counts + 0, w.sample);
+                                           w.hit_index, w.gq, nq, w.counts + 0, w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
+                    level_shadow_per_hit = shadow_per_hit;
+                    level_gather_per_hit = gather_per_hit;
                 }
                 if (single_level) {
                     // rayTrace spawns nothing when no material refracts and the mirror extension is
                     // off: this level is the last one and the host need not wait to learn that.
                     // The shadow-ray count is summed on the device and read with the frame's end.
                     hipLaunchKernelGGL(k_add_count, dim3(1), dim3(1), 0, st, w.counts + 1, w.work + 8);
-                    hipLaunchKernelGGL(k_add_count, dim3(1), dim3(1), 0, st, w.counts + 2, w.work + 9);
                     HIP_TRY(hipGetLastError());
+                    single_shadow_per_hit = level_shadow_per_hit;
+                    single_gather_per_hit = level_gather_per_hit;
                     break;
                 }
                 // one readback per level: next queue length and (Whitted) shadow rays traced
-                HIP_TRY(hipMemcpyAsync(w.host_counts, w.counts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(w.host_counts, w.counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 count = w.host_counts[0];
-                local.rays_shadow += w.host_counts[1];
-                local.rays_secondary += w.host_counts[2];      // gather rays are layer+1 shootRay calls
+                local.rays_shadow += (uint64_t)w.host_counts[1] * level_shadow_per_hit;
+                local.rays_secondary += (uint64_t)w.host_counts[1] * level_gather_per_hit;  // gather rays are layer+1 shootRay calls
                 cur ^= 1;
                 ++level;
             }
@@ -887,10 +893,13 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         HIP_TRY(hipMemcpyAsync(w.host_work, w.work, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(w.host_work + 10, w.work + 10, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     }
-    if (single_level) HIP_TRY(hipMemcpyAsync(w.host_work + 8, w.work + 8, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (single_level) HIP_TRY(hipMemcpyAsync(w.host_work + 8, w.work + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (stats) HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (single_level) { local.rays_shadow += w.host_work[8]; local.rays_secondary += w.host_work[9]; }
+    if (single_level) {     // every chunk and pass of such a frame is shaded at layer 0
+        local.rays_shadow += w.host_work[8] * single_shadow_per_hit;
+        local.rays_secondary += w.host_work[8] * single_gather_per_hit;
+    }
     if (stats) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));

@@ -33,16 +33,22 @@ struct RayQueue {
     double *hit_depth;
 };
 
+// Light rays of one level.  A hit with compact index h (its place among the level's hits) owns
+// the entries m * seg + h, m = 0 .. samples-1, where seg is the number of rays in the shaded
+// queue: sample-major over the whole level, so for one m neighbouring lanes touch neighbouring
+// entries in all three kernels.  The origin is shared by a hit's samples and stored once, at h.
 struct ShadowQueue {
-    double *ox, *oy, *oz, *dx, *dy, *dz;
+    double *ox, *oy, *oz;                   // per hit
+    double *dx, *dy, *dz;                   // per entry
     double *limit;                          // light distance: hits beyond it do not matter
     double *hit_depth;
 };
 
 // the gather rays of GLOBAL_LIGHTING (Raytracer-Noah-Desktop.cpp:499-524): closest-hit queries
-// whose hit (or miss) and distance are all that is used
+// whose hit (or miss) and distance are all that is used; laid out like the shadow queue
 struct GatherQueue {
-    double *ox, *oy, *oz, *dx, *dy, *dz;
+    double *ox, *oy, *oz;                   // per hit
+    double *dx, *dy, *dz;                   // per entry
     int32_t *hit_prim;
     double *hit_depth;
 };
@@ -57,11 +63,11 @@ struct RenderParams {
     uint32_t n;                 // pixel_multisample_n
     uint32_t shadow_per_hit;    // sum over lights of samples
     uint32_t queue_cap;         // entries a ray queue can hold; writes beyond are dropped and
-    uint32_t shadow_cap;        //   the host turns the overshooting count into RTX_ERR_LIMIT
+                                //   the host turns the overshooting count into RTX_ERR_LIMIT
+    uint32_t seg;               // rays in the queue being shaded = stride between a hit's shadow / gather entries
     // GLOBAL_LIGHTING at the level being shaded (all rays of a level share their layer):
     uint32_t gather_samples;    // globalSamples per light (:500); 0 = off
     uint32_t gather_traced;     // 1 when layer+1 <= MAXBOUNCES, i.e. the nested call shoots its ray
-    uint32_t gather_cap;
     uint32_t atomic_samples;    // 1: several rays of one launch may add to the same sample slot
 };
 
@@ -635,6 +641,33 @@ RTX_DEV void add_static_efficiency(Counters g, const Work<true>& w)
 }
 RTX_DEV void add_static_efficiency(Counters, const Work<false>&) {}
 
+// Which ray a thread (or a refilled lane) works on.  Flat queues (seg == 0): ray i of the first
+// min(n, *n_device) entries, origin and direction at i.  Light-ray queues (seg != 0, n = samples
+// * seg): the level's *n_device hits times n / seg samples.  They are enumerated in tiles of
+// kRayTile hits, sample-major within a tile -- ray i is hit h = t * kRayTile + j, sample m, with
+// i = (t * samples + m) * kRayTile + j -- so that a wavefront's lanes are neighbouring hits of one
+// sample (neighbouring entries m * seg + h, origins at h) while the samples of a tile are walked
+// soon after one another, when the parts of the BVH they need are still in cache.  The last tile
+// may be partial: ray_place() says whether i names a ray at all.
+constexpr uint32_t kRayTile = 256;
+RTX_DEV uint32_t ray_total(uint32_t n, const uint32_t* __restrict__ n_device, uint32_t seg)
+{
+    if (seg == 0) return n_device ? min(n, *n_device) : n;
+    const uint32_t tiles = (*n_device + kRayTile - 1) / kRayTile;
+    return tiles * kRayTile * (n / seg);        // <= n + kRayTile * samples: the host keeps that below 2^32
+}
+RTX_DEV bool ray_place(uint32_t i, uint32_t n, const uint32_t* __restrict__ n_device, uint32_t seg, uint32_t& entry,
+                       uint32_t& origin)
+{
+    if (seg == 0) { entry = origin = i; return true; }
+    const uint32_t samples = n / seg;
+    const uint32_t group = i / kRayTile, j = i % kRayTile;
+    const uint32_t t = group / samples, m = group - t * samples;
+    origin = t * kRayTile + j;
+    entry = m * seg + origin;
+    return origin < *n_device;
+}
+
 // shootRay for caller-supplied rays (rtx_trace_closest).  MODE 0 walks in the reference's
 // order and reports leaf sequences; MODE 1 (culled KD walk) and 3 (BVH) are the render
 // path's walks, for which the leaf outputs describe nothing the reference does.
@@ -683,16 +716,17 @@ template <bool COUNT, int MODE>
 __global__ void __launch_bounds__(kTraceBlock)
 k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
              const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
-             const double* __restrict__ limit, uint32_t n, const uint32_t* __restrict__ n_device, uint32_t linear,
-             int32_t* hit_prim, double* hit_depth, Counters g)
+             const double* __restrict__ limit, uint32_t n, const uint32_t* __restrict__ n_device, uint32_t seg,
+             uint32_t linear, int32_t* hit_prim, double* hit_depth, Counters g)
 {
     __shared__ int32_t stack[kStack * kTraceBlock];
-    uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
+    const uint32_t ray = blockIdx.x * kTraceBlock + threadIdx.x;
     // the grid is sized for n; when the real queue length is only known on the device
     // (n_device), the surplus workgroups leave here
-    if (n_device) n = min(n, *n_device);
-    if (i >= n) return;
-    d3 o = mk(ox[i], oy[i], oz[i]), d = mk(dx[i], dy[i], dz[i]);
+    if (ray >= ray_total(n, n_device, seg)) return;
+    uint32_t i, at;
+    if (!ray_place(ray, n, n_device, seg, i, at)) return;
+    d3 o = mk(ox[at], oy[at], oz[at]), d = mk(dx[i], dy[i], dz[i]);
     Work<COUNT> w;
     int32_t bp = -1; double bd = kInf;
     bool settled = false;
@@ -734,13 +768,14 @@ template <bool COUNT, bool ANYHIT>
 __global__ void __launch_bounds__(kTraceBlock)
 k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
                const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
-               const double* __restrict__ limit, uint32_t n, const uint32_t* __restrict__ n_device, uint32_t refill_at,
-               uint32_t rays_per_wave, int32_t* hit_prim, double* hit_depth, uint32_t* cand, Counters g)
+               const double* __restrict__ limit, uint32_t n, const uint32_t* __restrict__ n_device, uint32_t seg,
+               uint32_t refill_at, uint32_t rays_per_wave, int32_t* hit_prim, double* hit_depth, uint32_t* cand, Counters g)
 {
     __shared__ int32_t stack_mem[kStack * kTraceBlock];
     int32_t* const stack = stack_mem + threadIdx.x;
     const uint32_t lane = threadIdx.x;              // one wave per workgroup
-    if (n_device) n = min(n, *n_device);
+    const uint32_t n_entries = n;
+    n = ray_total(n, n_device, seg);
     if ((unsigned long long)blockIdx.x * rays_per_wave >= n) return;
     bool have = false;          // this lane is walking a ray
     bool pending = false;       // this lane holds a ray whose result is not stored yet
@@ -775,10 +810,10 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
             if (!have) {
                 const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t idx = cur + below;
-                if (idx < end) {
-                    ray = idx;
-                    o = mk(ox[idx], oy[idx], oz[idx]); d = mk(dx[idx], dy[idx], dz[idx]);
-                    if constexpr (ANYHIT) lim = limit[idx];
+                uint32_t at = 0;
+                if (idx < end && ray_place(idx, n_entries, n_device, seg, ray, at)) {
+                    o = mk(ox[at], oy[at], oz[at]); d = mk(dx[ray], dy[ray], dz[ray]);
+                    if constexpr (ANYHIT) lim = limit[ray];
                     inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
                     exact = isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
                     abs_margin = 1e-9 * (s.scene_scale + __builtin_fmax(fabs(o.x), __builtin_fmax(fabs(o.y), fabs(o.z))));
@@ -886,16 +921,17 @@ template <bool COUNT>
 __global__ void __launch_bounds__(kTraceBlock)
 k_verify(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
          const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
-         uint32_t n, const uint32_t* __restrict__ n_device, const uint32_t* __restrict__ cand, int32_t* hit_prim,
-         double* hit_depth, Counters g)
+         uint32_t n, const uint32_t* __restrict__ n_device, uint32_t seg, const uint32_t* __restrict__ cand,
+         int32_t* hit_prim, double* hit_depth, Counters g)
 {
     __shared__ int32_t stack[kStack * kTraceBlock];
-    uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
-    if (n_device) n = min(n, *n_device);
-    if (i >= n) return;
+    const uint32_t ray = blockIdx.x * kTraceBlock + threadIdx.x;
+    if (ray >= ray_total(n, n_device, seg)) return;
+    uint32_t i, at;
+    if (!ray_place(ray, n, n_device, seg, i, at)) return;
     const uint32_t c = cand[i];
     if (c == kCandSettled) return;
-    const d3 o = mk(ox[i], oy[i], oz[i]), d = mk(dx[i], dy[i], dz[i]);
+    const d3 o = mk(ox[at], oy[at], oz[at]), d = mk(dx[i], dy[i], dz[i]);
     Work<COUNT> w;
     bool ok = false;
     if (c != kCandReference && !(c & kCandTie)) {
@@ -1174,16 +1210,15 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
 }
 
 // ---- rayTrace (Raytracer-Noah-Desktop.cpp:452-564), first half: emit the light rays -----------------
-// Hit rays get shadow_per_hit shadow-queue entries, shadow_stride[i] apart from shadow_base[i] on,
-// and with GLOBAL_LIGHTING n_lights * gather_samples gather-queue entries, the same stride apart
-// from gather_base[i] on.  Random numbers are drawn in the reference's order: per light first
-// the SquareLight samples, then the gather directions.  GATHER = false compiles the gather out
-// (it costs registers, hence resident waves, even when it does not run).
+// A hit gets the compact index h = hit_index[i] and with it the shadow-queue entries m * seg + h
+// (m over the lights' samples) and, with GLOBAL_LIGHTING, the gather-queue entries of the same
+// form (m over lights x gather samples).  Random numbers are drawn in the reference's order: per
+// light first the SquareLight samples, then the gather directions.  GATHER = false compiles the
+// gather out (it costs registers, hence resident waves, even when it does not run).
 template <bool GATHER>
 __global__ void __launch_bounds__(kBlock)
-k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, uint32_t* shadow_count,
-                  uint32_t* shadow_base, uint32_t* shadow_stride, GatherQueue gq, uint32_t* gather_count,
-                  uint32_t* gather_base, double* sample)
+k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, uint32_t* hit_count,
+                  uint32_t* hit_index, GatherQueue gq, double* sample)
 {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool hit = false;
@@ -1197,48 +1232,39 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
     }
     const bool lit = !(p.d.flags & RTX_FLAG_NO_LIGHTING) && s.n_lights > 0;
     const uint32_t gather_samples = GATHER ? p.gather_samples : 0u;
-    const uint32_t gather_per_hit = (GATHER && lit && p.gather_traced) ? s.n_lights * gather_samples : 0u;
+    const bool gather_traced = GATHER && lit && p.gather_traced && gather_samples > 0;
     bool emit = hit && lit && (p.shadow_per_hit > 0 || gather_samples > 0);
     __shared__ uint32_t reserve_lds[kBlock / 64 + 2];
-    // the workgroup's entries are laid out sample-major: entry (hit j of the workgroup, sample m)
-    // sits at block_base + m * block_hits + j, so that for one m the lanes write neighbours
-    uint32_t block_hits = 0, block_base = 0, rank = 0, gblock_base = 0;
-    block_reserve(emit, shadow_count, p.shadow_per_hit, reserve_lds, &block_hits, &block_base, &rank);
-    if constexpr (GATHER) {
-        if (gather_per_hit) block_reserve(emit, gather_count, gather_per_hit, reserve_lds, nullptr, &gblock_base);
-    }
-    const uint32_t base = block_base + rank;
-    if (i < n) {
-        shadow_base[i] = base; shadow_stride[i] = block_hits;
-        if (gather_per_hit) gather_base[i] = gblock_base + rank;
-    }
-    const bool shadow_fits = (unsigned long long)block_base + (unsigned long long)block_hits * p.shadow_per_hit <= p.shadow_cap;
-    const bool gather_fits = (unsigned long long)gblock_base + (unsigned long long)block_hits * gather_per_hit <= p.gather_cap;
-    if (emit && shadow_fits && gather_fits) {
+    const uint32_t h_index = block_reserve(emit, hit_count, 1, reserve_lds);     // < seg: at most one per ray
+    if (i < n) hit_index[i] = h_index;
+    if (emit) {
         d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
         Hit h;
         prim_full(s, (uint32_t)q.hit_prim[i], o, d, h);
         uint32_t slot = q.slot[i];
         Rng rng = ray_rng(p, q, i, slot);
         d3 from = h.position + (h.normal * p.d.bias);
-        uint32_t k = base, g = gblock_base + rank;
+        // Light::getRay starts every light ray of this hit at `from` (Ray.cpp:3-8 keeps the origin)
+        sq.ox[h_index] = from.x; sq.oy[h_index] = from.y; sq.oz[h_index] = from.z;
+        if constexpr (GATHER) {
+            if (gather_traced) { gq.ox[h_index] = h.position.x; gq.oy[h_index] = h.position.y; gq.oz[h_index] = h.position.z; }
+        }
+        uint32_t k = h_index, g = h_index;
         for (uint32_t li = 0; li < s.n_lights; ++li) {
             const rtx_light& l = s.lights[li];
             uint32_t samples = l.multisample ? p.d.light_multisample_n * p.d.light_multisample_n : 1u;
-            for (uint32_t sm = 0; sm < samples; ++sm, k += block_hits) {
+            for (uint32_t sm = 0; sm < samples; ++sm, k += p.seg) {
                 double u0 = 0.0, u1 = 0.0;
                 if (l.kind == RTX_LIGHT_SQUARE) { u0 = rng_next(rng); u1 = rng_next(rng); }
                 Ray lr = light_ray(l, from, u0, u1);
-                sq.ox[k] = lr.o.x; sq.oy[k] = lr.o.y; sq.oz[k] = lr.o.z;
                 sq.dx[k] = lr.d.x; sq.dy[k] = lr.d.y; sq.dz[k] = lr.d.z;
                 sq.limit[k] = light_distance(l, lr);
             }
             if constexpr (GATHER) {
-                if (gather_per_hit) {
-                    for (uint32_t gm = 0; gm < gather_samples; ++gm, g += block_hits) {
+                if (gather_traced) {
+                    for (uint32_t gm = 0; gm < gather_samples; ++gm, g += p.seg) {
                         // Ray lightRay(minRayResult.position, randomHemisphericalVector(normal)) (:503-505)
                         Ray gr = make_ray(h.position, random_hemispherical_desktop(h.normal, rng));
-                        gq.ox[g] = gr.o.x; gq.oy[g] = gr.o.y; gq.oz[g] = gr.o.z;
                         gq.dx[g] = gr.d.x; gq.dy[g] = gr.d.y; gq.dz[g] = gr.d.z;
                     }
                 } else {
@@ -1253,9 +1279,8 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
 // second half: direct lighting from the shadow results, the gather's sum, blend, spawn children
 template <bool GATHER>
 __global__ void __launch_bounds__(kBlock)
-k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, const uint32_t* shadow_base,
-                  const uint32_t* shadow_stride, GatherQueue gq, const uint32_t* gather_base, RayQueue next,
-                  uint32_t* next_count, double* sample)
+k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, const uint32_t* hit_index,
+                  GatherQueue gq, RayQueue next, uint32_t* next_count, double* sample)
 {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool spawn_t = false, spawn_r = false;
@@ -1276,20 +1301,19 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
             local = material_color(s, m, h.u, h.v);
         } else {
             d3 direct = mk(0, 0, 0), global = mk(0, 0, 0);
-            uint32_t k = shadow_base[i];
-            const uint32_t stride = shadow_stride[i];
-            uint32_t g = (GATHER && p.gather_samples && p.gather_traced) ? gather_base[i] : 0u;
+            const uint32_t h_index = hit_index[i];
+            const uint32_t stride = p.seg;
+            uint32_t k = h_index, g = h_index;
             for (uint32_t li = 0; li < s.n_lights; ++li) {
                 const rtx_light& l = s.lights[li];
                 uint32_t samples = l.multisample ? p.d.light_multisample_n * p.d.light_multisample_n : 1u;
                 for (uint32_t sm = 0; sm < samples; ++sm, k += stride) {
-                    Ray lr;
-                    lr.o = mk(sq.ox[k], sq.oy[k], sq.oz[k]);
-                    lr.d = mk(sq.dx[k], sq.dy[k], sq.dz[k]);
-                    double ldist = light_distance(l, lr);
+                    // light->getDistance(lightRay) (:490) was evaluated when the ray was made
+                    const double ldist = sq.limit[k];
                     if (ldist < sq.hit_depth[k]) {
+                        const d3 ld = mk(sq.dx[k], sq.dy[k], sq.dz[k]);
                         double att = light_attenuation(l, ldist, p.d.attenuation);
-                        direct = direct + lighting(s, inv_dir, lr.d, h.normal, h.u, h.v, att, m, ld3(l.color));
+                        direct = direct + lighting(s, inv_dir, ld, h.normal, h.u, h.v, att, m, ld3(l.color));
                     }
                 }
                 direct = direct / (double)samples;          // inside the light loop (:498)
@@ -1303,7 +1327,7 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
                             d3 gd = mk(gq.dx[g], gq.dy[g], gq.dz[g]);
                             double dist = t;
                             if ((s.prim_info[gp] & 3u) != RTX_PRIM_TRIANGLE) {
-                                d3 go = mk(gq.ox[g], gq.oy[g], gq.oz[g]);
+                                d3 go = mk(gq.ox[h_index], gq.oy[h_index], gq.oz[h_index]);
                                 dist = distance3(go, go + (gd * t));
                             }
                             double att = light_attenuation(l, dist, p.d.attenuation);
