@@ -110,7 +110,7 @@ T* carve(char*& p, size_t count)
 size_t queue_bytes(size_t cap)
 {
     auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
-    size_t per_queue = 10 * al(cap * 8) + 4 * al(cap * 4) + al(cap * 4) + al(cap * 8);
+    size_t per_queue = 9 * al(cap * 8) + 3 * al(cap * 4) + al(cap * 4) + al(cap * 8);
     return 2 * per_queue + 2 * al(cap * 4) + al(cap * 3 * 8) + 6 * al(cap * 8);
 }
 
@@ -153,8 +153,7 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap, size_t gather
             q.ox = carve<double>(p, cap); q.oy = carve<double>(p, cap); q.oz = carve<double>(p, cap);
             q.dx = carve<double>(p, cap); q.dy = carve<double>(p, cap); q.dz = carve<double>(p, cap);
             q.wx = carve<double>(p, cap); q.wy = carve<double>(p, cap); q.wz = carve<double>(p, cap);
-            q.ior = carve<double>(p, cap);
-            q.slot = carve<uint32_t>(p, cap); q.layer = carve<uint32_t>(p, cap);
+            q.slot = carve<uint32_t>(p, cap);
             q.branch = carve<uint32_t>(p, cap); q.counter = carve<uint32_t>(p, cap);
             q.hit_prim = carve<int32_t>(p, cap); q.hit_depth = carve<double>(p, cap);
         }
@@ -796,8 +795,11 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 local.max_queue = std::max(local.max_queue, count);
                 if (level == 0) local.rays_primary += count; else local.rays_secondary += count;
                 timer.begin();
-                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, count, nullptr, 0, rd->flags, q.hit_prim, q.hit_depth,
-                                  count_work);
+                // the shading kernels recompute the hit from its id: the depth is only kept for
+                // the refilled walk's verification pass
+                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, count, nullptr, 0, rd->flags, q.hit_prim,
+                                  (rd->flags & RTX_FLAG_REFILL_LANES) ? q.hit_depth : nullptr, count_work);
+                p.layer = level;
                 if (rc != RTX_OK) return rc;
                 timer.end(&local.ms_traverse);
                 local.traverse_launches++;

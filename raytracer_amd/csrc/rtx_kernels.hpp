@@ -25,9 +25,9 @@ constexpr int kStack = 24;              // per-lane stack entries: KD depth is c
 struct RayQueue {
     double *ox, *oy, *oz, *dx, *dy, *dz;    // Ray (direction already normalised by Ray::Ray)
     double *wx, *wy, *wz;                   // weight this ray's radiance carries into its sample
-    double *ior;                            // currentIOR argument
+    // (the reference's currentIOR argument is passed down and never read, Raytracer.cpp:217,
+    //  Raytracer-Noah-Desktop.cpp:452; the recursion depth is the same for all rays of a level)
     uint32_t *slot;                         // sample slot the ray contributes to
-    uint32_t *layer;                        // recursion depth
     uint32_t *branch, *counter;             // random stream (branch code, next draw index)
     int32_t *hit_prim;                      // filled by k_trace_pool
     double *hit_depth;
@@ -64,6 +64,7 @@ struct RenderParams {
     uint32_t shadow_per_hit;    // sum over lights of samples
     uint32_t queue_cap;         // entries a ray queue can hold; writes beyond are dropped and
                                 //   the host turns the overshooting count into RTX_ERR_LIMIT
+    uint32_t layer;             // recursion depth of the rays being shaded (the same for a whole level)
     uint32_t seg;               // rays in the queue being shaded = stride between a hit's shadow / gather entries
     // GLOBAL_LIGHTING at the level being shaded (all rays of a level share their layer):
     uint32_t gather_samples;    // globalSamples per light (:500); 0 = off
@@ -741,7 +742,7 @@ k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__
         trace_lane<COUNT>(s, o, d, linear != 0, stack + threadIdx.x, bp, bd, w, nullptr, 0);
     }
     if (hit_prim) hit_prim[i] = bp;
-    hit_depth[i] = bd;
+    if (hit_depth) hit_depth[i] = bd;
     add_counters(g, w);
     add_static_efficiency(g, w);
 }
@@ -998,13 +999,12 @@ RTX_DEV uint32_t block_reserve(bool pred, uint32_t* counter, uint32_t per_item, 
     return lds[kBlock / 64] + (lds[wave] + prefix) * per_item;
 }
 
-RTX_DEV void push_ray(const RayQueue& q, uint32_t j, const Ray& r, d3 w, double ior, uint32_t slot, uint32_t layer,
-                      uint32_t branch, uint32_t counter)
+RTX_DEV void push_ray(const RayQueue& q, uint32_t j, const Ray& r, d3 w, uint32_t slot, uint32_t branch, uint32_t counter)
 {
     q.ox[j] = r.o.x; q.oy[j] = r.o.y; q.oz[j] = r.o.z;
     q.dx[j] = r.d.x; q.dy[j] = r.d.y; q.dz[j] = r.d.z;
     q.wx[j] = w.x; q.wy[j] = w.y; q.wz[j] = w.z;
-    q.ior[j] = ior; q.slot[j] = slot; q.layer[j] = layer; q.branch[j] = branch; q.counter[j] = counter;
+    q.slot[j] = slot; q.branch[j] = branch; q.counter[j] = counter;
 }
 
 // camera rays of one chunk (Raytracer.cpp:676-700); one thread per sample slot
@@ -1029,7 +1029,7 @@ k_generate(RenderParams p, RayQueue q)
     double offy = (double)sy * (cy / (double)(p.n + 1));
     d3 v = normalize3((on_screen + mk(offx, offy, 0.0)) - eye);
     // ray i of the first queue is sample slot i
-    push_ray(q, slot, make_ray(eye, v), mk(1.0, 1.0, 1.0), 1.0, slot, 0u, 0u, 0u);
+    push_ray(q, slot, make_ray(eye, v), mk(1.0, 1.0, 1.0), slot, 0u, 0u);
 }
 
 RTX_DEV void sample_add(const RenderParams& p, double* sample, uint32_t slot, d3 v)
@@ -1131,9 +1131,10 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
     const bool live = j0 < n;
     const uint32_t i = live ? (perm ? perm[j0] : j0) : 0u;
     bool spawn = false;
-    Ray child; d3 cw = mk(0, 0, 0); double cior = 1.0; uint32_t slot = 0, layer = 0, cbranch = 0, ccounter = 0;
+    Ray child; d3 cw = mk(0, 0, 0); uint32_t slot = 0, cbranch = 0, ccounter = 0;
+    const uint32_t layer = p.layer;
     if (live) {
-        slot = q.slot[i]; layer = q.layer[i];
+        slot = q.slot[i];
         d3 w = mk(q.wx[i], q.wy[i], q.wz[i]);
         d3 clear = ld3(p.d.clear_color);
         int32_t prim = q.hit_prim[i];
@@ -1197,7 +1198,7 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
                         d3 diffuse = (one * diff) * matC;
                         cw = w * (spec + (kD * diffuse));
                     }
-                    cior = ni; cbranch = rng.branch; ccounter = rng.counter;
+                    cbranch = rng.branch; ccounter = rng.counter;
                     if (layer + 1 > p.d.max_depth) sample_add(p, sample, slot, cw * (clear * 0.1));   // :220-222
                     else spawn = true;
                 }
@@ -1206,7 +1207,7 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
     }
     __shared__ uint32_t reserve_lds[kBlock / 64 + 2];
     uint32_t j = block_reserve(spawn, next_count, 1, reserve_lds);
-    if (spawn && j < p.queue_cap) push_ray(next, j, child, cw, cior, slot, layer + 1, cbranch, ccounter);
+    if (spawn && j < p.queue_cap) push_ray(next, j, child, cw, slot, cbranch, ccounter);
 }
 
 // ---- rayTrace (Raytracer-Noah-Desktop.cpp:452-564), first half: emit the light rays -----------------
@@ -1285,9 +1286,10 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool spawn_t = false, spawn_r = false;
     Ray child_t, child_r; d3 wt = mk(0, 0, 0), wr = mk(0, 0, 0);
-    double ni = 1.0; uint32_t slot = 0, layer = 0, branch = 0, counter = 0;
+    double ni = 1.0; uint32_t slot = 0, branch = 0, counter = 0;
+    const uint32_t layer = p.layer;
     if (i < n && q.hit_prim[i] >= 0) {
-        slot = q.slot[i]; layer = q.layer[i]; branch = q.branch[i]; counter = q.counter[i];
+        slot = q.slot[i]; branch = q.branch[i]; counter = q.counter[i];
         d3 w = mk(q.wx[i], q.wy[i], q.wz[i]);
         d3 clear = ld3(p.d.clear_color);
         d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
@@ -1370,9 +1372,9 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
     }
     __shared__ uint32_t reserve_lds[kBlock / 64 + 2];
     uint32_t jt = block_reserve(spawn_t, next_count, 1, reserve_lds);
-    if (spawn_t && jt < p.queue_cap) push_ray(next, jt, child_t, wt, ni, slot, layer + 1, branch, counter);
+    if (spawn_t && jt < p.queue_cap) push_ray(next, jt, child_t, wt, slot, branch, counter);
     uint32_t jr = block_reserve(spawn_r, next_count, 1, reserve_lds);
-    if (spawn_r && jr < p.queue_cap) push_ray(next, jr, child_r, wr, ni, slot, layer + 1, branch | (1u << (layer & 31u)), 0u);
+    if (spawn_r && jr < p.queue_cap) push_ray(next, jr, child_r, wr, slot, branch | (1u << (layer & 31u)), 0u);
 }
 
 // drawBuffer[x + y*frameX] += colorAcum / double(n*n)  (Raytracer.cpp:705-710): the
