@@ -81,8 +81,8 @@ struct Workspace {
     uint32_t* perm = nullptr;               // shading order (material sort)
     uint32_t* bins = nullptr;               // 2 * kBins: histogram, next free place per bin
     double* sample = nullptr;               // 3 per slot
-    uint32_t* counts = nullptr;             // [0] next queue, [1] hits of the level being shaded
-    unsigned long long* work = nullptr;     // 8 work counters, [8] hits of single-level frames, [10..11] SIMD efficiency
+    uint32_t* counts = nullptr;             // ring of four (queue length, lit hits) pairs, indexed by level % 4
+    unsigned long long* work = nullptr;     // 8 work counters, [8] shadow rays, [9] gather rays, [10..11] SIMD efficiency, [12] secondary rays
     uint32_t* host_counts = nullptr;        // pinned
     unsigned long long* host_work = nullptr;
     ~Workspace()
@@ -138,11 +138,11 @@ int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap, size_t gather
     Workspace& w = sc->ws;
     if (!w.counts) {
         HIP_TRY(hipMalloc(&w.counts, 8 * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&w.work, 12 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&w.work, 16 * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc(&w.bins, 2 * kBins * sizeof(uint32_t)));
         HIP_TRY(hipMemset(w.bins, 0, 2 * kBins * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc(&w.host_counts, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc(&w.host_work, 12 * sizeof(unsigned long long)));
+        HIP_TRY(hipHostMalloc(&w.host_counts, 8 * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc(&w.host_work, 16 * sizeof(unsigned long long)));
     }
     if (cap > w.capacity) {
         if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.capacity = 0; }
@@ -746,6 +746,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     pixels_per_chunk = std::min<uint64_t>(pixels_per_chunk, padded_pixels);
     size_t cap = (size_t)pixels_per_chunk * nn;
     size_t queue_cap = cap * growth;
+    const size_t fan_out = growth > 1 ? 2 : 1;
     if (queue_cap * std::max<uint64_t>(gather_per_hit0, 1) > 0xf0000000ull || queue_cap * (uint64_t)std::max<uint32_t>(shadow_per_hit, 1) > 0xf0000000ull)
         return fail(RTX_ERR_LIMIT, "light-ray queue of the smallest chunk exceeds 2^32 entries (%u shadow rays per hit)", shadow_per_hit);
     int rc = ensure_workspace(sc, queue_cap, whitted ? queue_cap * std::max<uint32_t>(shadow_per_hit, 1) : 0,
@@ -769,9 +770,18 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         HIP_TRY(hipMemsetAsync(w.work, 0, 8 * sizeof(unsigned long long), st));
         HIP_TRY(hipMemsetAsync(w.work + 10, 0, 2 * sizeof(unsigned long long), st));
     }
+    // rayTrace spawns nothing when no material refracts and the mirror extension is off
     const bool single_level = whitted && !sc->may_refract && !(rd->flags & RTX_FLAG_WHITTED_REFLECT);
-    if (single_level) HIP_TRY(hipMemsetAsync(w.work + 8, 0, sizeof(unsigned long long), st));
-    uint32_t single_shadow_per_hit = 0, single_gather_per_hit = 0;
+    // ray totals by kind are summed on the device (k_level_totals) and read with the frame's end
+    HIP_TRY(hipMemsetAsync(w.work + 8, 0, 2 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(w.work + 12, 0, sizeof(unsigned long long), st));
+    // Queue lengths live on the device: counts[2k] is the length of the queue of level L (k = L % 4),
+    // counts[2k+1] the number of its lit hits.  The host reads a length back only to stop early and
+    // to size the next launches tightly, which pays when launches are long; short levels are
+    // launched for an upper bound of their length without waiting (surplus workgroups leave at
+    // once), with a readback every fourth level.
+    const bool sync_every_level = fan_out > 1 || (rd->flags & RTX_FLAG_SORT_MATERIAL);
+    const uint32_t kLongLevel = 4u << 20;
 
     for (uint32_t pass = rd->first_pass; pass < rd->first_pass + rd->passes; ++pass) {
         p.pass = pass;
@@ -780,59 +790,62 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
             p.chunk_pixels = (uint32_t)std::min<uint64_t>(pixels_per_chunk, padded_pixels - t0);
             size_t slots = (size_t)p.chunk_pixels * nn;
             HIP_TRY(hipMemsetAsync(w.sample, 0, slots * 3 * sizeof(double), st));
-            HIP_TRY(hipMemsetAsync(w.counts, 0, 4 * sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(w.counts, 0, 8 * sizeof(uint32_t), st));
             timer.begin();
             hipLaunchKernelGGL(k_generate, grid_for(slots), dim3(kBlock), 0, st, p, w.q[0]);
             HIP_TRY(hipGetLastError());
             timer.end(&local.ms_generate);
-            uint32_t count = (uint32_t)slots;        // one camera ray per sample slot
+            local.rays_primary += slots;
+            local.max_queue = std::max<uint32_t>(local.max_queue, (uint32_t)slots);
+            uint32_t bound = (uint32_t)slots;           // one camera ray per sample slot
+            bool exact = true;                          // `bound` is the queue's length, not just a bound of it
             int cur = 0;
-            uint32_t level = 0;
-            uint32_t level_shadow_per_hit = 0, level_gather_per_hit = 0;    // light rays per lit hit at the level just shaded
-            while (count > 0) {
-                if (count > queue_cap) return fail(RTX_ERR_LIMIT, "ray queue overflow (%u > %zu)", count, queue_cap);
+            for (uint32_t level = 0; bound > 0; ++level) {
                 RayQueue& q = w.q[cur];
                 RayQueue& nq = w.q[cur ^ 1];
-                local.max_queue = std::max(local.max_queue, count);
-                if (level == 0) local.rays_primary += count; else local.rays_secondary += count;
+                uint32_t* len = w.counts + 2 * (level % 4);
+                uint32_t* hits = len + 1;
+                uint32_t* next_len = w.counts + 2 * ((level + 1) % 4);
+                const uint32_t* n_dev = exact ? nullptr : len;
                 timer.begin();
                 // the shading kernels recompute the hit from its id: the depth is only kept for
                 // the refilled walk's verification pass
-                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, count, nullptr, 0, rd->flags, q.hit_prim,
+                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, bound, n_dev, 0, rd->flags, q.hit_prim,
                                   (rd->flags & RTX_FLAG_REFILL_LANES) ? q.hit_depth : nullptr, count_work);
-                p.layer = level;
                 if (rc != RTX_OK) return rc;
                 timer.end(&local.ms_traverse);
                 local.traverse_launches++;
-                HIP_TRY(hipMemsetAsync(w.counts, 0, 2 * sizeof(uint32_t), st));
+                p.layer = level;
+                HIP_TRY(hipMemsetAsync(next_len, 0, 2 * sizeof(uint32_t), st));
+                uint32_t shadow_mult = 0, gather_mult = 0;
                 if (!whitted) {
                     timer.begin();
                     const uint32_t* perm = nullptr;
-                    if (rd->flags & RTX_FLAG_SORT_MATERIAL) {
-                        hipLaunchKernelGGL(k_bin_count, grid_for(count), dim3(kBlock), 0, st, sc->d, q.hit_prim, count, w.bins);
+                    if (rd->flags & RTX_FLAG_SORT_MATERIAL) {       // exact lengths here (sync_every_level)
+                        hipLaunchKernelGGL(k_bin_count, grid_for(bound), dim3(kBlock), 0, st, sc->d, q.hit_prim, bound, w.bins);
                         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBins), 0, st, w.bins);
-                        hipLaunchKernelGGL(k_bin_scatter, grid_for(count), dim3(kBlock), 0, st, sc->d, q.hit_prim, count, w.bins, w.perm);
+                        hipLaunchKernelGGL(k_bin_scatter, grid_for(bound), dim3(kBlock), 0, st, sc->d, q.hit_prim, bound, w.bins, w.perm);
                         perm = w.perm;
                     }
-                    hipLaunchKernelGGL(k_shade_path, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, perm, nq, w.counts + 0, w.sample);
+                    hipLaunchKernelGGL(k_shade_path, grid_for(bound), dim3(kBlock), 0, st, sc->d, p, q, bound, n_dev, perm, nq, next_len, w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                 } else {
                     p.gather_samples = gather_samples_at(level);
                     p.gather_traced = level + 1 <= rd->max_depth ? 1u : 0u;
-                    p.seg = count;
+                    p.seg = bound;
                     const uint32_t gather_per_hit = p.gather_traced ? p.gather_samples * sc->d.n_lights : 0u;
-                    const uint64_t gather_max = (uint64_t)count * gather_per_hit;
-                    const uint64_t shadow_max = (uint64_t)count * shadow_per_hit;
+                    const uint64_t gather_max = (uint64_t)bound * gather_per_hit;
+                    const uint64_t shadow_max = (uint64_t)bound * shadow_per_hit;
                     if (gather_max > w.gather_capacity) return fail(RTX_ERR_LIMIT, "gather queue overflow");
                     if (shadow_max > w.shadow_capacity) return fail(RTX_ERR_LIMIT, "shadow queue overflow");
                     timer.begin();
                     if (p.gather_samples)
-                        hipLaunchKernelGGL(k_shade_whitted_a<true>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                           w.counts + 1, w.hit_index, w.gq, w.sample);
+                        hipLaunchKernelGGL(k_shade_whitted_a<true>, grid_for(bound), dim3(kBlock), 0, st, sc->d, p, q, bound, n_dev, w.sq,
+                                           hits, w.hit_index, w.gq, w.sample);
                     else
-                        hipLaunchKernelGGL(k_shade_whitted_a<false>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                           w.counts + 1, w.hit_index, w.gq, w.sample);
+                        hipLaunchKernelGGL(k_shade_whitted_a<false>, grid_for(bound), dim3(kBlock), 0, st, sc->d, p, q, bound, n_dev, w.sq,
+                                           hits, w.hit_index, w.gq, w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
                     // the number of hits stays on the device: the launches are sized for the most
@@ -840,7 +853,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                     if (shadow_max > 0) {
                         timer.begin();
                         rc = launch_trace(sc, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, w.sq.limit, (uint32_t)shadow_max,
-                                          w.counts + 1, count, rd->flags, nullptr, w.sq.hit_depth, count_work);
+                                          hits, bound, rd->flags, nullptr, w.sq.hit_depth, count_work);
                         if (rc != RTX_OK) return rc;
                         timer.end(&local.ms_shadow);
                         local.traverse_launches++;
@@ -850,41 +863,38 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                         // closest-hit query each (their colour is discarded, :509-510)
                         timer.begin();
                         rc = launch_trace(sc, w.gq.ox, w.gq.oy, w.gq.oz, w.gq.dx, w.gq.dy, w.gq.dz, nullptr, (uint32_t)gather_max,
-                                          w.counts + 1, count, rd->flags, w.gq.hit_prim, w.gq.hit_depth, count_work);
+                                          hits, bound, rd->flags, w.gq.hit_prim, w.gq.hit_depth, count_work);
                         if (rc != RTX_OK) return rc;
                         timer.end(&local.ms_traverse);
                         local.traverse_launches++;
                     }
                     timer.begin();
                     if (p.gather_samples)
-                        hipLaunchKernelGGL(k_shade_whitted_b<true>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                           w.hit_index, w.gq, nq, w.counts + 0, w.sample);
+                        hipLaunchKernelGGL(k_shade_whitted_b<true>, grid_for(bound), dim3(kBlock), 0, st, sc->d, p, q, bound, n_dev, w.sq,
+                                           w.hit_index, w.gq, nq, next_len, w.sample);
                     else
-                        hipLaunchKernelGGL(k_shade_whitted_b<false>, grid_for(count), dim3(kBlock), 0, st, sc->d, p, q, count, w.sq,
-                                           w.hit_index, w.gq, nq, w.counts + 0, w.sample);
+                        hipLaunchKernelGGL(k_shade_whitted_b<false>, grid_for(bound), dim3(kBlock), 0, st, sc->d, p, q, bound, n_dev, w.sq,
+                                           w.hit_index, w.gq, nq, next_len, w.sample);
                     HIP_TRY(hipGetLastError());
                     timer.end(&local.ms_shade);
-                    level_shadow_per_hit = shadow_per_hit;
-                    level_gather_per_hit = gather_per_hit;
+                    shadow_mult = shadow_per_hit;
+                    gather_mult = gather_per_hit;       // gather rays are layer+1 shootRay calls
                 }
-                if (single_level) {
-                    // rayTrace spawns nothing when no material refracts and the mirror extension is
-                    // off: this level is the last one and the host need not wait to learn that.
-                    // The shadow-ray count is summed on the device and read with the frame's end.
-                    hipLaunchKernelGGL(k_add_count, dim3(1), dim3(1), 0, st, w.counts + 1, w.work + 8);
-                    HIP_TRY(hipGetLastError());
-                    single_shadow_per_hit = level_shadow_per_hit;
-                    single_gather_per_hit = level_gather_per_hit;
-                    break;
-                }
-                // one readback per level: next queue length and (Whitted) shadow rays traced
-                HIP_TRY(hipMemcpyAsync(w.host_counts, w.counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                count = w.host_counts[0];
-                local.rays_shadow += (uint64_t)w.host_counts[1] * level_shadow_per_hit;
-                local.rays_secondary += (uint64_t)w.host_counts[1] * level_gather_per_hit;  // gather rays are layer+1 shootRay calls
+                hipLaunchKernelGGL(k_level_totals, dim3(1), dim3(1), 0, st, next_len, hits, w.work, shadow_mult, gather_mult);
+                HIP_TRY(hipGetLastError());
+                // rays are only spawned for layers up to max_depth (Raytracer.cpp:220, Desktop :456)
+                if (single_level || level >= rd->max_depth) break;
                 cur ^= 1;
-                ++level;
+                if (sync_every_level || bound >= kLongLevel || level % 4 == 3) {
+                    HIP_TRY(hipMemcpyAsync(w.host_counts, next_len, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    bound = w.host_counts[0];
+                    exact = true;
+                    if (bound > queue_cap) return fail(RTX_ERR_LIMIT, "ray queue overflow (%u > %zu)", bound, queue_cap);
+                    local.max_queue = std::max(local.max_queue, bound);
+                } else {
+                    exact = false;      // without the mirror extension a level is never longer than the one before
+                }
             }
             timer.begin();
             hipLaunchKernelGGL(k_resolve, grid_for(p.chunk_pixels), dim3(kBlock), 0, st, p, w.sample, accum);
@@ -896,13 +906,12 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         HIP_TRY(hipMemcpyAsync(w.host_work, w.work, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(w.host_work + 10, w.work + 10, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     }
-    if (single_level) HIP_TRY(hipMemcpyAsync(w.host_work + 8, w.work + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(w.host_work + 8, w.work + 8, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(w.host_work + 12, w.work + 12, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (stats) HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (single_level) {     // every chunk and pass of such a frame is shaded at layer 0
-        local.rays_shadow += w.host_work[8] * single_shadow_per_hit;
-        local.rays_secondary += w.host_work[8] * single_gather_per_hit;
-    }
+    local.rays_shadow += w.host_work[8];
+    local.rays_secondary += w.host_work[9] + w.host_work[12];
     if (stats) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));

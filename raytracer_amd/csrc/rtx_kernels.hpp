@@ -1124,9 +1124,10 @@ k_bin_scatter(DScene s, const int32_t* __restrict__ hit_prim, uint32_t n, uint32
 // `perm` (optional) lists the queue entries in the order they are to be shaded: thread j
 // shades ray perm[j].
 __global__ void __launch_bounds__(kBlock)
-k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* __restrict__ perm, RayQueue next,
-             uint32_t* next_count, double* sample)
+k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* __restrict__ n_device,
+             const uint32_t* __restrict__ perm, RayQueue next, uint32_t* next_count, double* sample)
 {
+    if (n_device) n = min(n, *n_device);        // the grid is sized for an upper bound of the queue length
     const uint32_t j0 = blockIdx.x * kBlock + threadIdx.x;
     const bool live = j0 < n;
     const uint32_t i = live ? (perm ? perm[j0] : j0) : 0u;
@@ -1218,9 +1219,10 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
 // gather out (it costs registers, hence resident waves, even when it does not run).
 template <bool GATHER>
 __global__ void __launch_bounds__(kBlock)
-k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, uint32_t* hit_count,
-                  uint32_t* hit_index, GatherQueue gq, double* sample)
+k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* __restrict__ n_device, ShadowQueue sq,
+                  uint32_t* hit_count, uint32_t* hit_index, GatherQueue gq, double* sample)
 {
+    if (n_device) n = min(n, *n_device);
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool hit = false;
     if (i < n) {
@@ -1280,9 +1282,10 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue 
 // second half: direct lighting from the shadow results, the gather's sum, blend, spawn children
 template <bool GATHER>
 __global__ void __launch_bounds__(kBlock)
-k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, ShadowQueue sq, const uint32_t* hit_index,
-                  GatherQueue gq, RayQueue next, uint32_t* next_count, double* sample)
+k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* __restrict__ n_device, ShadowQueue sq,
+                  const uint32_t* hit_index, GatherQueue gq, RayQueue next, uint32_t* next_count, double* sample)
 {
+    if (n_device) n = min(n, *n_device);
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool spawn_t = false, spawn_r = false;
     Ray child_t, child_r; d3 wt = mk(0, 0, 0), wr = mk(0, 0, 0);
@@ -1400,8 +1403,15 @@ k_resolve(RenderParams p, const double* __restrict__ sample, float* accum)
     accum[at + 2] += (float)px.z;
 }
 
-// total += *count (one thread): keeps a per-level counter's value when the host does not read it
-__global__ void k_add_count(const uint32_t* count, unsigned long long* total) { *total += *count; }
+// Ray totals of one level (one thread), so that the host need not read the per-level counters:
+// work[12] += rays spawned for the next level, work[8] += shadow rays, work[9] += gather rays.
+__global__ void k_level_totals(const uint32_t* next_len, const uint32_t* hits, unsigned long long* work,
+                               uint32_t shadow_per_hit, uint32_t gather_per_hit)
+{
+    work[12] += *next_len;
+    work[8] += (unsigned long long)*hits * shadow_per_hit;
+    work[9] += (unsigned long long)*hits * gather_per_hit;
+}
 
 // ---- present (Raytracer.cpp:720-725, :422, :90-105) ------------------------------------------------
 // linear float -> 8-bit sRGB as an sRGB framebuffer stores it: clamp, transfer function, round
