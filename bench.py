@@ -131,7 +131,7 @@ def main():
             work[k] += getattr(st, k)
 
     for s in range(args.warmup):
-        step_fn(s, abi.FLAG_STAGE_TIMES)
+        step_fn(s, abi.FLAG_TRACE_TIMES)
     drain()
 
     def sync():
@@ -144,7 +144,7 @@ def main():
     rays = launches = 0
     ms_trav = 0.0
     for s in range(args.steps):
-        st = step_fn(args.warmup + s, abi.FLAG_STAGE_TIMES)
+        st = step_fn(args.warmup + s, abi.FLAG_TRACE_TIMES)      # HIP events around the traversal launches only
         rays += st.rays
         launches += st.traverse_launches
         ms_trav += st.ms_traverse + st.ms_shadow

@@ -206,10 +206,13 @@ enum {
                                            inside the light loop
                                            (Raytracer-Noah-Desktop.cpp:69,499-524), with
                                            rtx_render_desc.global_samples = MONTE_CARLO_SAMPLES */
-    RTX_FLAG_REFILL_LANES    = 1u << 11 /* the BVH walk refills finished lanes from the queue
+    RTX_FLAG_REFILL_LANES    = 1u << 11,/* the BVH walk refills finished lanes from the queue
                                            instead of keeping one ray per lane for the life of
                                            a wavefront (same results; fewer idle lanes but
                                            measured slower, for comparison)                   */
+    RTX_FLAG_TRACE_TIMES     = 1u << 12 /* fill only ms_traverse and ms_shadow of the statistics: the
+                                           traversal launches; fewer events on the stream than
+                                           RTX_FLAG_STAGE_TIMES                               */
 };
 
 /* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;
@@ -256,7 +259,8 @@ typedef struct rtx_stats {
     uint64_t fallback_rays;         /* rays the fast walk could not certify and
                                        re-traced in reference order               */
     /* device time per stage in milliseconds (HIP events on the library stream);
-       ms_total always, the per-stage sums with RTX_FLAG_STAGE_TIMES */
+       ms_total always, the per-stage sums with RTX_FLAG_STAGE_TIMES (ms_traverse and
+       ms_shadow also with RTX_FLAG_TRACE_TIMES) */
     double ms_generate;
     double ms_traverse;
     double ms_shade;

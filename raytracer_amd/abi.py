@@ -37,6 +37,7 @@ FLAG_RENDER_WALK = 1 << 8
 FLAG_SORT_MATERIAL = 1 << 9
 FLAG_GLOBAL_LIGHTING = 1 << 10
 FLAG_REFILL_LANES = 1 << 11
+FLAG_TRACE_TIMES = 1 << 12
 
 TONEMAP_NONE, TONEMAP_CBRT = 0, 1
 

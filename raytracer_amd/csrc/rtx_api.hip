@@ -759,6 +759,8 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     rtx_stats local;
     std::memset(&local, 0, sizeof local);
     StageTimer timer(stats != nullptr && (rd->flags & RTX_FLAG_STAGE_TIMES), st);
+    // the traversal launches alone (ms_traverse, ms_shadow): a third of the events of all stages
+    StageTimer trace_timer(stats != nullptr && (rd->flags & (RTX_FLAG_STAGE_TIMES | RTX_FLAG_TRACE_TIMES)), st);
     struct Events {
         hipEvent_t a = nullptr, b = nullptr;
         ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
@@ -807,13 +809,13 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 uint32_t* hits = len + 1;
                 uint32_t* next_len = w.counts + 2 * ((level + 1) % 4);
                 const uint32_t* n_dev = exact ? nullptr : len;
-                timer.begin();
+                trace_timer.begin();
                 // the shading kernels recompute the hit from its id: the depth is only kept for
                 // the refilled walk's verification pass
                 rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, bound, n_dev, 0, rd->flags, q.hit_prim,
                                   (rd->flags & RTX_FLAG_REFILL_LANES) ? q.hit_depth : nullptr, count_work);
                 if (rc != RTX_OK) return rc;
-                timer.end(&local.ms_traverse);
+                trace_timer.end(&local.ms_traverse);
                 local.traverse_launches++;
                 p.layer = level;
                 HIP_TRY(hipMemsetAsync(next_len, 0, 2 * sizeof(uint32_t), st));
@@ -851,21 +853,21 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                     // the number of hits stays on the device: the launches are sized for the most
                     // there can be and read the real number themselves
                     if (shadow_max > 0) {
-                        timer.begin();
+                        trace_timer.begin();
                         rc = launch_trace(sc, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, w.sq.limit, (uint32_t)shadow_max,
                                           hits, bound, rd->flags, nullptr, w.sq.hit_depth, count_work);
                         if (rc != RTX_OK) return rc;
-                        timer.end(&local.ms_shadow);
+                        trace_timer.end(&local.ms_shadow);
                         local.traverse_launches++;
                     }
                     if (gather_max > 0) {
                         // the gather's nested rayTrace calls, reduced to what reaches the image: one
                         // closest-hit query each (their colour is discarded, :509-510)
-                        timer.begin();
+                        trace_timer.begin();
                         rc = launch_trace(sc, w.gq.ox, w.gq.oy, w.gq.oz, w.gq.dx, w.gq.dy, w.gq.dz, nullptr, (uint32_t)gather_max,
                                           hits, bound, rd->flags, w.gq.hit_prim, w.gq.hit_depth, count_work);
                         if (rc != RTX_OK) return rc;
-                        timer.end(&local.ms_traverse);
+                        trace_timer.end(&local.ms_traverse);
                         local.traverse_launches++;
                     }
                     timer.begin();
@@ -917,6 +919,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         local.ms_total = ms;
         timer.collect();
+        trace_timer.collect();
         if (count_work) {
             local.branch_visits = w.host_work[0]; local.leaf_visits = w.host_work[1]; local.aabb_tests = w.host_work[2];
             local.triangle_tests = w.host_work[3]; local.sphere_tests = w.host_work[4]; local.hits_accepted = w.host_work[5];
