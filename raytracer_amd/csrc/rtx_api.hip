@@ -791,10 +791,8 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
             p.chunk_t0 = (uint32_t)t0;
             p.chunk_pixels = (uint32_t)std::min<uint64_t>(pixels_per_chunk, padded_pixels - t0);
             size_t slots = (size_t)p.chunk_pixels * nn;
-            HIP_TRY(hipMemsetAsync(w.sample, 0, slots * 3 * sizeof(double), st));
-            HIP_TRY(hipMemsetAsync(w.counts, 0, 8 * sizeof(uint32_t), st));
             timer.begin();
-            hipLaunchKernelGGL(k_generate, grid_for(slots), dim3(kBlock), 0, st, p, w.q[0]);
+            hipLaunchKernelGGL(k_generate, grid_for(slots), dim3(kBlock), 0, st, p, w.q[0], w.sample, w.counts);
             HIP_TRY(hipGetLastError());
             timer.end(&local.ms_generate);
             local.rays_primary += slots;
@@ -818,7 +816,6 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 trace_timer.end(&local.ms_traverse);
                 local.traverse_launches++;
                 p.layer = level;
-                HIP_TRY(hipMemsetAsync(next_len, 0, 2 * sizeof(uint32_t), st));
                 uint32_t shadow_mult = 0, gather_mult = 0;
                 if (!whitted) {
                     timer.begin();
@@ -882,7 +879,8 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                     shadow_mult = shadow_per_hit;
                     gather_mult = gather_per_hit;       // gather rays are layer+1 shootRay calls
                 }
-                hipLaunchKernelGGL(k_level_totals, dim3(1), dim3(1), 0, st, next_len, hits, w.work, shadow_mult, gather_mult);
+                hipLaunchKernelGGL(k_level_totals, dim3(1), dim3(1), 0, st, next_len, hits, w.work, shadow_mult, gather_mult,
+                                   w.counts + 2 * ((level + 2) % 4));
                 HIP_TRY(hipGetLastError());
                 // rays are only spawned for layers up to max_depth (Raytracer.cpp:220, Desktop :456)
                 if (single_level || level >= rd->max_depth) break;

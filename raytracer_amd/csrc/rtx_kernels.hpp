@@ -1007,11 +1007,13 @@ RTX_DEV void push_ray(const RayQueue& q, uint32_t j, const Ray& r, d3 w, uint32_
     q.slot[j] = slot; q.branch[j] = branch; q.counter[j] = counter;
 }
 
-// camera rays of one chunk (Raytracer.cpp:676-700); one thread per sample slot
+// camera rays of one chunk (Raytracer.cpp:676-700); one thread per sample slot.  Also clears
+// the chunk's state: its slot of the sample accumulator and the queue-length counters.
 __global__ void __launch_bounds__(kBlock)
-k_generate(RenderParams p, RayQueue q)
+k_generate(RenderParams p, RayQueue q, double* sample, uint32_t* counts)
 {
     uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot < 8u) counts[slot] = 0u;
     uint32_t nn = p.n * p.n;
     uint32_t total = p.chunk_pixels * nn;
     if (slot >= total || slot >= p.queue_cap) return;
@@ -1028,6 +1030,7 @@ k_generate(RenderParams p, RayQueue q)
     double offx = (double)sx * (cx / (double)(p.n + 1));
     double offy = (double)sy * (cy / (double)(p.n + 1));
     d3 v = normalize3((on_screen + mk(offx, offy, 0.0)) - eye);
+    sample[3 * (size_t)slot + 0] = 0.0; sample[3 * (size_t)slot + 1] = 0.0; sample[3 * (size_t)slot + 2] = 0.0;
     // ray i of the first queue is sample slot i
     push_ray(q, slot, make_ray(eye, v), mk(1.0, 1.0, 1.0), slot, 0u, 0u);
 }
@@ -1405,12 +1408,14 @@ k_resolve(RenderParams p, const double* __restrict__ sample, float* accum)
 
 // Ray totals of one level (one thread), so that the host need not read the per-level counters:
 // work[12] += rays spawned for the next level, work[8] += shadow rays, work[9] += gather rays.
+// It also clears the counter pair of the level after next, which the next level's kernels fill.
 __global__ void k_level_totals(const uint32_t* next_len, const uint32_t* hits, unsigned long long* work,
-                               uint32_t shadow_per_hit, uint32_t gather_per_hit)
+                               uint32_t shadow_per_hit, uint32_t gather_per_hit, uint32_t* pair_after_next)
 {
     work[12] += *next_len;
     work[8] += (unsigned long long)*hits * shadow_per_hit;
     work[9] += (unsigned long long)*hits * gather_per_hit;
+    pair_after_next[0] = 0u; pair_after_next[1] = 0u;
 }
 
 // ---- present (Raytracer.cpp:720-725, :422, :90-105) ------------------------------------------------
