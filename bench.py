@@ -48,6 +48,11 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frame16", action="store_true", help="skip the 16-spp soft-shadow frame timing")
+    ap.add_argument("--serial-chunks", action="store_true",
+                    help="render a frame's two half-frame chunks one after the other instead of on two streams: "
+                         "launches then run alone, which is how the per-launch figures of the roofline are best read")
+    ap.add_argument("--no-serial-leg", action="store_true",
+                    help="skip the untimed repeat of the frames with chunks one after the other (roofline.serial)")
     ap.add_argument("--walk", choices=["bvh", "kd-culled", "reference"], default="bvh",
                     help="bvh: candidates from the library's BVH, verified against the reference's KD walk "
                          "(default render path); kd-culled: the reference's KD tree walked with culling; "
@@ -86,6 +91,8 @@ def main():
     desc = scene.frame(0.0)
     kd = scene.kd_stats()
     kflags = {"bvh": 0, "kd-culled": abi.FLAG_KD_CULLED, "reference": abi.FLAG_REFERENCE_ORDER}[args.walk]
+    if args.serial_chunks:
+        kflags |= abi.FLAG_SERIAL_CHUNKS
     stream = torch.cuda.current_stream().cuda_stream
     ds = device.DeviceScene(desc, stream=stream)
 
@@ -152,6 +159,20 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
 
+    # The same frames once more, untimed, with the two chunks one after the other: every traversal
+    # launch then has the machine to itself, which is what a per-launch bandwidth should be read on.
+    serial = None
+    if not args.serial_chunks and not args.no_serial_leg:
+        s_ms, s_launches = 0.0, 0
+        for s in range(args.steps):
+            st = ds.render_device(rd_for(args.warmup + s, abi.FLAG_TRACE_TIMES | abi.FLAG_SERIAL_CHUNKS), fb.data_ptr())
+            s_ms += st.ms_traverse + st.ms_shadow
+            s_launches += st.traverse_launches
+        if s_ms > 0 and s_launches:
+            s_achieved = alg_bytes / (s_ms / 1e3) / 1e9
+            serial = {"achieved": round(s_achieved, 2), "frac": round(s_achieved / HBM_PEAK_GBS, 4),
+                      "avg_launch_ms": round(s_ms / s_launches, 4), "launches": s_launches}
+
     tt = torch.tensor([elapsed, float(rays), ms_trav, float(launches), float(alg_bytes)], dtype=torch.float64, device=comm_dev)
     if world > 1:
         mx = tt.clone()
@@ -207,6 +228,10 @@ def main():
                 "kernel": "k_trace (KD traversal + leaf scans), primary and shadow launches",
                 "algorithmic_bytes_per_ray": round(alg_bytes / max(rays, 1), 1),
                 "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
+                # two half-frame chunks run on two streams: a launch shares the machine with the other
+                # chunk's kernels, so its duration (and `achieved`) is that of a kernel on part of the GPU
+                "launches_overlap": not args.serial_chunks,
+                "serial": serial,
                 "fp64_valu_tflops": round(flops / (ms_trav / 1e3) / 1e12, 3) if ms_trav > 0 else None,
                 "fp64_valu_frac": round(flops / (ms_trav / 1e3) / 1e12 / FP64_PEAK_TFLOPS, 4) if ms_trav > 0 else None,
             },

@@ -210,9 +210,13 @@ enum {
                                            instead of keeping one ray per lane for the life of
                                            a wavefront (same results; fewer idle lanes but
                                            measured slower, for comparison)                   */
-    RTX_FLAG_TRACE_TIMES     = 1u << 12 /* fill only ms_traverse and ms_shadow of the statistics: the
+    RTX_FLAG_TRACE_TIMES     = 1u << 12,/* fill only ms_traverse and ms_shadow of the statistics: the
                                            traversal launches; fewer events on the stream than
                                            RTX_FLAG_STAGE_TIMES                               */
+    RTX_FLAG_SERIAL_CHUNKS   = 1u << 13 /* render the tile's chunks one after the other on the
+                                           scene's stream instead of two at a time on the
+                                           library's two streams (same image; launches then do
+                                           not overlap, so their durations can be measured)   */
 };
 
 /* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;

@@ -119,7 +119,20 @@ size_t queue_bytes(size_t cap)
 struct rtx_scene {
     DScene d;
     DeviceBuffers buffers;
-    Workspace ws;
+    // Two lanes: a frame's chunks are rendered two at a time on the library's own streams, so that
+    // while one chunk's launch drains (a traversal launch ends in a tail of a few long rays) the
+    // other chunk's kernels fill the machine.  A lane owns its queues and counters.
+    Workspace ws[2];
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    hipEvent_t fork_event = nullptr, join_event[2] = {nullptr, nullptr};
+    ~rtx_scene()
+    {
+        for (int k = 0; k < 2; ++k) {
+            if (lane_stream[k]) (void)hipStreamDestroy(lane_stream[k]);
+            if (join_event[k]) (void)hipEventDestroy(join_event[k]);
+        }
+        if (fork_event) (void)hipEventDestroy(fork_event);
+    }
     hipStream_t stream = nullptr;
     int device = 0;
     uint32_t kd_depth = 0;
@@ -133,9 +146,8 @@ struct rtx_scene {
 
 namespace {
 
-int ensure_workspace(rtx_scene* sc, size_t cap, size_t shadow_cap, size_t gather_cap, bool with_cand)
+int ensure_workspace(Workspace& w, size_t cap, size_t shadow_cap, size_t gather_cap, bool with_cand)
 {
-    Workspace& w = sc->ws;
     if (!w.counts) {
         HIP_TRY(hipMalloc(&w.counts, 8 * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&w.work, 16 * sizeof(unsigned long long)));
@@ -630,9 +642,9 @@ int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* directi
 // limit == nullptr: closest hit; otherwise any hit with depth <= limit[i] (shadow rays).
 // seg == 0: the first min(n, *n_device) rays of a flat queue; seg != 0: a light-ray queue of
 // n = samples * seg entries, of which *n_device hits x samples are in use (see ray_place).
-static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const double* oz, const double* dx,
-                        const double* dy, const double* dz, const double* limit, uint32_t n, const uint32_t* n_device,
-                        uint32_t seg, uint32_t flags, int32_t* hit_prim, double* hit_depth, bool count)
+static int launch_trace(rtx_scene* sc, Workspace& ws, hipStream_t stream, const double* ox, const double* oy, const double* oz,
+                        const double* dx, const double* dy, const double* dz, const double* limit, uint32_t n,
+                        const uint32_t* n_device, uint32_t seg, uint32_t flags, int32_t* hit_prim, double* hit_depth, bool count)
 {
     uint32_t linear = (flags & RTX_FLAG_LINEAR_SCAN) ? 1u : 0u;
     int mode;
@@ -640,13 +652,13 @@ static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const
     else if (flags & RTX_FLAG_KD_CULLED) mode = limit ? 2 : 1;
     else mode = limit ? 4 : 3;
     Counters g;
-    g.c = count ? sc->ws.work : nullptr;
+    g.c = count ? ws.work : nullptr;
     // threads to launch: light-ray queues are enumerated in whole tiles of hits (ray_total)
     uint64_t threads = n;
     if (seg) threads = ((uint64_t)seg + kRayTile - 1) / kRayTile * kRayTile * (n / seg);
     if (threads > 0xffffffffull) return fail(RTX_ERR_LIMIT, "more than 2^32 light rays in one launch: lower RTX_MAX_PATHS");
     dim3 grid = trace_grid_for(threads), block(kTraceBlock);
-    if (mode >= 3 && (flags & RTX_FLAG_REFILL_LANES) && n <= sc->ws.cand_capacity) {
+    if (mode >= 3 && (flags & RTX_FLAG_REFILL_LANES) && n <= ws.cand_capacity) {
         // lanes refilled from the wave's own range of the queue; ranges shrink for small launches
         // so that every resident wave slot gets several
         const int anyhit = limit ? 1 : 0;
@@ -654,21 +666,21 @@ static int launch_trace(rtx_scene* sc, const double* ox, const double* oy, const
         const uint32_t rays_per_wave = (uint32_t)std::min<uint64_t>(sc->refill_range, std::max<uint64_t>(64, (threads / (slots * 4)) / 64 * 64));
         dim3 pgrid((unsigned)((threads + rays_per_wave - 1) / rays_per_wave));
 #define RTX_LAUNCH_REFILL(COUNT, ANYHIT)                                                                              \
-    hipLaunchKernelGGL((k_trace_refill<COUNT, ANYHIT>), pgrid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
-                       n_device, seg, sc->refill_at, rays_per_wave, hit_prim, hit_depth, sc->ws.cand, g)
+    hipLaunchKernelGGL((k_trace_refill<COUNT, ANYHIT>), pgrid, block, 0, stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
+                       n_device, seg, sc->refill_at, rays_per_wave, hit_prim, hit_depth, ws.cand, g)
         if (count) { if (anyhit) RTX_LAUNCH_REFILL(true, true); else RTX_LAUNCH_REFILL(true, false); }
         else { if (anyhit) RTX_LAUNCH_REFILL(false, true); else RTX_LAUNCH_REFILL(false, false); }
 #undef RTX_LAUNCH_REFILL
         HIP_TRY(hipGetLastError());
-        if (count) hipLaunchKernelGGL(k_verify<true>, grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, n, n_device,
-                                      seg, sc->ws.cand, hit_prim, hit_depth, g);
-        else hipLaunchKernelGGL(k_verify<false>, grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, n, n_device,
-                                seg, sc->ws.cand, hit_prim, hit_depth, g);
+        if (count) hipLaunchKernelGGL(k_verify<true>, grid, block, 0, stream, sc->d, ox, oy, oz, dx, dy, dz, n, n_device,
+                                      seg, ws.cand, hit_prim, hit_depth, g);
+        else hipLaunchKernelGGL(k_verify<false>, grid, block, 0, stream, sc->d, ox, oy, oz, dx, dy, dz, n, n_device,
+                                seg, ws.cand, hit_prim, hit_depth, g);
         HIP_TRY(hipGetLastError());
         return RTX_OK;
     }
 #define RTX_LAUNCH_TRACE(COUNT, MODE)                                                                                  \
-    hipLaunchKernelGGL((k_trace_pool<COUNT, MODE>), grid, block, 0, sc->stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
+    hipLaunchKernelGGL((k_trace_pool<COUNT, MODE>), grid, block, 0, stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
                        n_device, seg, linear, hit_prim, hit_depth, g)
 #define RTX_LAUNCH_MODES(COUNT)                                                                   \
     switch (mode) {                                                                               \
@@ -744,39 +756,51 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     if (whitted && shadow_per_hit) pixels_per_chunk = std::min(pixels_per_chunk, pixels_for(max_light_rays, shadow_per_hit));
     if (gather_per_hit0) pixels_per_chunk = std::min(pixels_per_chunk, pixels_for(max_gather, gather_per_hit0));
     pixels_per_chunk = std::min<uint64_t>(pixels_per_chunk, padded_pixels);
-    size_t cap = (size_t)pixels_per_chunk * nn;
-    size_t queue_cap = cap * growth;
+    // Chunks are rendered two at a time, each on a stream of its own: the launch tails and the
+    // one-workgroup kernels of one chunk overlap with the other's launches.  The budgets are for
+    // both together; a tile that would fit one chunk is cut in two, and the number of chunks is
+    // even with equal sizes.  Small tiles stay in one piece: halves would only make the tails longer.
+    const bool serial = (rd->flags & RTX_FLAG_SERIAL_CHUNKS) != 0 || padded_pixels * nn < (1u << 20);
+    if (!serial) {
+        const uint64_t half = std::max<uint64_t>(64, pixels_per_chunk / 2 / 64 * 64);
+        uint64_t n_chunks = (padded_pixels + half - 1) / half;
+        n_chunks += n_chunks & 1;
+        pixels_per_chunk = std::max<uint64_t>(64, std::min(half, ((padded_pixels + n_chunks - 1) / n_chunks + 63) / 64 * 64));
+    }
+    const int n_lanes = serial ? 1 : 2;
+    const size_t cap = (size_t)pixels_per_chunk * nn;
+    const size_t queue_cap = cap * growth;
     const size_t fan_out = growth > 1 ? 2 : 1;
     if (queue_cap * std::max<uint64_t>(gather_per_hit0, 1) > 0xf0000000ull || queue_cap * (uint64_t)std::max<uint32_t>(shadow_per_hit, 1) > 0xf0000000ull)
         return fail(RTX_ERR_LIMIT, "light-ray queue of the smallest chunk exceeds 2^32 entries (%u shadow rays per hit)", shadow_per_hit);
-    int rc = ensure_workspace(sc, queue_cap, whitted ? queue_cap * std::max<uint32_t>(shadow_per_hit, 1) : 0,
+    int rc = RTX_OK;
+    for (int k = 0; k < n_lanes; ++k) {
+        rc = ensure_workspace(sc->ws[k], queue_cap, whitted ? queue_cap * std::max<uint32_t>(shadow_per_hit, 1) : 0,
                               (size_t)(queue_cap * gather_per_hit0), (rd->flags & RTX_FLAG_REFILL_LANES) != 0);
-    if (rc != RTX_OK) return rc;
-    Workspace& w = sc->ws;
-    hipStream_t st = sc->stream;
-    p.queue_cap = (uint32_t)std::min<size_t>(w.capacity, 0xffffffffu);
+        if (rc != RTX_OK) return rc;
+    }
+    if (n_lanes > 1 && !sc->lane_stream[0]) {
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipStreamCreateWithFlags(&sc->lane_stream[k], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&sc->join_event[k], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&sc->fork_event, hipEventDisableTiming));
+    }
+    hipStream_t user = sc->stream;
 
     rtx_stats local;
     std::memset(&local, 0, sizeof local);
-    StageTimer timer(stats != nullptr && (rd->flags & RTX_FLAG_STAGE_TIMES), st);
-    // the traversal launches alone (ms_traverse, ms_shadow): a third of the events of all stages
-    StageTimer trace_timer(stats != nullptr && (rd->flags & (RTX_FLAG_STAGE_TIMES | RTX_FLAG_TRACE_TIMES)), st);
     struct Events {
         hipEvent_t a = nullptr, b = nullptr;
         ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
     } ev;
     hipEvent_t& ev0 = ev.a;
     hipEvent_t& ev1 = ev.b;
-    if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, st)); }
-    if (count_work) {
-        HIP_TRY(hipMemsetAsync(w.work, 0, 8 * sizeof(unsigned long long), st));
-        HIP_TRY(hipMemsetAsync(w.work + 10, 0, 2 * sizeof(unsigned long long), st));
-    }
+    if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, user)); }
+    if (n_lanes > 1) HIP_TRY(hipEventRecord(sc->fork_event, user));
+
     // rayTrace spawns nothing when no material refracts and the mirror extension is off
     const bool single_level = whitted && !sc->may_refract && !(rd->flags & RTX_FLAG_WHITTED_REFLECT);
-    // ray totals by kind are summed on the device (k_level_totals) and read with the frame's end
-    HIP_TRY(hipMemsetAsync(w.work + 8, 0, 2 * sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(w.work + 12, 0, sizeof(unsigned long long), st));
     // Queue lengths live on the device: counts[2k] is the length of the queue of level L (k = L % 4),
     // counts[2k+1] the number of its lit hits.  The host reads a length back only to stop early and
     // to size the next launches tightly, which pays when launches are long; short levels are
@@ -785,144 +809,219 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     const bool sync_every_level = fan_out > 1 || (rd->flags & RTX_FLAG_SORT_MATERIAL);
     const uint32_t kLongLevel = 4u << 20;
 
-    for (uint32_t pass = rd->first_pass; pass < rd->first_pass + rd->passes; ++pass) {
-        p.pass = pass;
-        for (uint64_t t0 = 0; t0 < padded_pixels; t0 += pixels_per_chunk) {
-            p.chunk_t0 = (uint32_t)t0;
-            p.chunk_pixels = (uint32_t)std::min<uint64_t>(pixels_per_chunk, padded_pixels - t0);
-            size_t slots = (size_t)p.chunk_pixels * nn;
-            timer.begin();
-            hipLaunchKernelGGL(k_generate, grid_for(slots), dim3(kBlock), 0, st, p, w.q[0], w.sample, w.counts);
-            HIP_TRY(hipGetLastError());
-            timer.end(&local.ms_generate);
-            local.rays_primary += slots;
-            local.max_queue = std::max<uint32_t>(local.max_queue, (uint32_t)slots);
-            uint32_t bound = (uint32_t)slots;           // one camera ray per sample slot
-            bool exact = true;                          // `bound` is the queue's length, not just a bound of it
-            int cur = 0;
-            for (uint32_t level = 0; bound > 0; ++level) {
-                RayQueue& q = w.q[cur];
-                RayQueue& nq = w.q[cur ^ 1];
-                uint32_t* len = w.counts + 2 * (level % 4);
-                uint32_t* hits = len + 1;
-                uint32_t* next_len = w.counts + 2 * ((level + 1) % 4);
-                const uint32_t* n_dev = exact ? nullptr : len;
-                trace_timer.begin();
-                // the shading kernels recompute the hit from its id: the depth is only kept for
-                // the refilled walk's verification pass
-                rc = launch_trace(sc, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, bound, n_dev, 0, rd->flags, q.hit_prim,
-                                  (rd->flags & RTX_FLAG_REFILL_LANES) ? q.hit_depth : nullptr, count_work);
-                if (rc != RTX_OK) return rc;
-                trace_timer.end(&local.ms_traverse);
-                local.traverse_launches++;
-                p.layer = level;
-                uint32_t shadow_mult = 0, gather_mult = 0;
-                if (!whitted) {
-                    timer.begin();
-                    const uint32_t* perm = nullptr;
-                    if (rd->flags & RTX_FLAG_SORT_MATERIAL) {       // exact lengths here (sync_every_level)
-                        hipLaunchKernelGGL(k_bin_count, grid_for(bound), dim3(kBlock), 0, st, sc->d, q.hit_prim, bound, w.bins);
-                        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBins), 0, st, w.bins);
-                        hipLaunchKernelGGL(k_bin_scatter, grid_for(bound), dim3(kBlock), 0, st, sc->d, q.hit_prim, bound, w.bins, w.perm);
-                        perm = w.perm;
-                    }
-                    hipLaunchKernelGGL(k_shade_path, grid_for(bound), dim3(kBlock), 0, st, sc->d, p, q, bound, n_dev, perm, nq, next_len, w.sample);
-                    HIP_TRY(hipGetLastError());
-                    timer.end(&local.ms_shade);
-                } else {
-                    p.gather_samples = gather_samples_at(level);
-                    p.gather_traced = level + 1 <= rd->max_depth ? 1u : 0u;
-                    p.seg = bound;
-                    const uint32_t gather_per_hit = p.gather_traced ? p.gather_samples * sc->d.n_lights : 0u;
-                    const uint64_t gather_max = (uint64_t)bound * gather_per_hit;
-                    const uint64_t shadow_max = (uint64_t)bound * shadow_per_hit;
-                    if (gather_max > w.gather_capacity) return fail(RTX_ERR_LIMIT, "gather queue overflow");
-                    if (shadow_max > w.shadow_capacity) return fail(RTX_ERR_LIMIT, "shadow queue overflow");
-                    timer.begin();
-                    if (p.gather_samples)
-                        hipLaunchKernelGGL(k_shade_whitted_a<true>, grid_for(bound), dim3(kBlock), 0, st, sc->d, p, q, bound, n_dev, w.sq,
-                                           hits, w.hit_index, w.gq, w.sample);
-                    else
-                        hipLaunchKernelGGL(k_shade_whitted_a<false>, grid_for(bound), dim3(kBlock), 0, st, sc->d, p, q, bound, n_dev, w.sq,
-                                           hits, w.hit_index, w.gq, w.sample);
-                    HIP_TRY(hipGetLastError());
-                    timer.end(&local.ms_shade);
-                    // the number of hits stays on the device: the launches are sized for the most
-                    // there can be and read the real number themselves
-                    if (shadow_max > 0) {
-                        trace_timer.begin();
-                        rc = launch_trace(sc, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, w.sq.limit, (uint32_t)shadow_max,
-                                          hits, bound, rd->flags, nullptr, w.sq.hit_depth, count_work);
-                        if (rc != RTX_OK) return rc;
-                        trace_timer.end(&local.ms_shadow);
-                        local.traverse_launches++;
-                    }
-                    if (gather_max > 0) {
-                        // the gather's nested rayTrace calls, reduced to what reaches the image: one
-                        // closest-hit query each (their colour is discarded, :509-510)
-                        trace_timer.begin();
-                        rc = launch_trace(sc, w.gq.ox, w.gq.oy, w.gq.oz, w.gq.dx, w.gq.dy, w.gq.dz, nullptr, (uint32_t)gather_max,
-                                          hits, bound, rd->flags, w.gq.hit_prim, w.gq.hit_depth, count_work);
-                        if (rc != RTX_OK) return rc;
-                        trace_timer.end(&local.ms_traverse);
-                        local.traverse_launches++;
-                    }
-                    timer.begin();
-                    if (p.gather_samples)
-                        hipLaunchKernelGGL(k_shade_whitted_b<true>, grid_for(bound), dim3(kBlock), 0, st, sc->d, p, q, bound, n_dev, w.sq,
-                                           w.hit_index, w.gq, nq, next_len, w.sample);
-                    else
-                        hipLaunchKernelGGL(k_shade_whitted_b<false>, grid_for(bound), dim3(kBlock), 0, st, sc->d, p, q, bound, n_dev, w.sq,
-                                           w.hit_index, w.gq, nq, next_len, w.sample);
-                    HIP_TRY(hipGetLastError());
-                    timer.end(&local.ms_shade);
-                    shadow_mult = shadow_per_hit;
-                    gather_mult = gather_per_hit;       // gather rays are layer+1 shootRay calls
-                }
-                hipLaunchKernelGGL(k_level_totals, dim3(1), dim3(1), 0, st, next_len, hits, w.work, shadow_mult, gather_mult,
-                                   w.counts + 2 * ((level + 2) % 4));
-                HIP_TRY(hipGetLastError());
-                // rays are only spawned for layers up to max_depth (Raytracer.cpp:220, Desktop :456)
-                if (single_level || level >= rd->max_depth) break;
-                cur ^= 1;
-                if (sync_every_level || bound >= kLongLevel || level % 4 == 3) {
-                    HIP_TRY(hipMemcpyAsync(w.host_counts, next_len, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                    HIP_TRY(hipStreamSynchronize(st));
-                    bound = w.host_counts[0];
-                    exact = true;
-                    if (bound > queue_cap) return fail(RTX_ERR_LIMIT, "ray queue overflow (%u > %zu)", bound, queue_cap);
-                    local.max_queue = std::max(local.max_queue, bound);
-                } else {
-                    exact = false;      // without the mirror extension a level is never longer than the one before
-                }
+    struct Lane {
+        Workspace* w = nullptr;
+        hipStream_t st = nullptr;
+        RenderParams p;
+        StageTimer timer, trace_timer;
+        uint32_t bound = 0, level = 0;
+        bool exact = true, alive = false, want_sync = false;
+        int cur = 0;
+        Lane(bool all, bool trace) : timer(all, nullptr), trace_timer(trace, nullptr) {}
+    };
+    const bool time_all = stats != nullptr && (rd->flags & RTX_FLAG_STAGE_TIMES);
+    // the traversal launches alone (ms_traverse, ms_shadow): a third of the events of all stages
+    const bool time_trace = stats != nullptr && (rd->flags & (RTX_FLAG_STAGE_TIMES | RTX_FLAG_TRACE_TIMES));
+    Lane lanes[2] = {Lane(time_all, time_trace), Lane(time_all, time_trace)};
+    for (int k = 0; k < n_lanes; ++k) {
+        Lane& L = lanes[k];
+        L.w = &sc->ws[k];
+        L.st = n_lanes > 1 ? sc->lane_stream[k] : user;
+        L.timer.stream = L.trace_timer.stream = L.st;
+        L.p = p;
+        L.p.queue_cap = (uint32_t)std::min<size_t>(L.w->capacity, 0xffffffffu);
+        if (n_lanes > 1) HIP_TRY(hipStreamWaitEvent(L.st, sc->fork_event, 0));
+        // work counters and ray totals by kind (k_level_totals) are summed on the device per lane
+        // and read with the frame's end
+        HIP_TRY(hipMemsetAsync(L.w->work, 0, 16 * sizeof(unsigned long long), L.st));
+    }
+
+    // an error return leaves nothing of this frame running on the library's streams
+    struct Drain {
+        Lane* lanes; int n; bool armed = true;
+        ~Drain() { if (armed) for (int k = 0; k < n; ++k) if (lanes[k].st) (void)hipStreamSynchronize(lanes[k].st); }
+    } drain{lanes, n_lanes > 1 ? n_lanes : 0};
+
+    // one level of a lane's chunk: traverse, shade, totals; afterwards the lane either is done with
+    // the chunk (resolve enqueued), wants its next queue length read back, or just goes on
+    auto enqueue_level = [&](Lane& L) -> int {
+        Workspace& w = *L.w;
+        hipStream_t st = L.st;
+        RenderParams& lp = L.p;
+        const uint32_t level = L.level, bound = L.bound;
+        RayQueue& q = w.q[L.cur];
+        RayQueue& nq = w.q[L.cur ^ 1];
+        uint32_t* len = w.counts + 2 * (level % 4);
+        uint32_t* hits = len + 1;
+        uint32_t* next_len = w.counts + 2 * ((level + 1) % 4);
+        const uint32_t* n_dev = L.exact ? nullptr : len;
+        L.trace_timer.begin();
+        // the shading kernels recompute the hit from its id: the depth is only kept for
+        // the refilled walk's verification pass
+        int r = launch_trace(sc, w, st, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, bound, n_dev, 0, rd->flags, q.hit_prim,
+                             (rd->flags & RTX_FLAG_REFILL_LANES) ? q.hit_depth : nullptr, count_work);
+        if (r != RTX_OK) return r;
+        L.trace_timer.end(&local.ms_traverse);
+        local.traverse_launches++;
+        lp.layer = level;
+        uint32_t shadow_mult = 0, gather_mult = 0;
+        if (!whitted) {
+            L.timer.begin();
+            const uint32_t* perm = nullptr;
+            if (rd->flags & RTX_FLAG_SORT_MATERIAL) {       // exact lengths here (sync_every_level)
+                hipLaunchKernelGGL(k_bin_count, grid_for(bound), dim3(kBlock), 0, st, sc->d, q.hit_prim, bound, w.bins);
+                hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBins), 0, st, w.bins);
+                hipLaunchKernelGGL(k_bin_scatter, grid_for(bound), dim3(kBlock), 0, st, sc->d, q.hit_prim, bound, w.bins, w.perm);
+                perm = w.perm;
             }
-            timer.begin();
-            hipLaunchKernelGGL(k_resolve, grid_for(p.chunk_pixels), dim3(kBlock), 0, st, p, w.sample, accum);
+            hipLaunchKernelGGL(k_shade_path, grid_for(bound), dim3(kBlock), 0, st, sc->d, lp, q, bound, n_dev, perm, nq, next_len, w.sample);
             HIP_TRY(hipGetLastError());
-            timer.end(&local.ms_resolve);
+            L.timer.end(&local.ms_shade);
+        } else {
+            lp.gather_samples = gather_samples_at(level);
+            lp.gather_traced = level + 1 <= rd->max_depth ? 1u : 0u;
+            lp.seg = bound;
+            const uint32_t gather_per_hit = lp.gather_traced ? lp.gather_samples * sc->d.n_lights : 0u;
+            const uint64_t gather_max = (uint64_t)bound * gather_per_hit;
+            const uint64_t shadow_max = (uint64_t)bound * shadow_per_hit;
+            if (gather_max > w.gather_capacity) return fail(RTX_ERR_LIMIT, "gather queue overflow");
+            if (shadow_max > w.shadow_capacity) return fail(RTX_ERR_LIMIT, "shadow queue overflow");
+            L.timer.begin();
+            if (lp.gather_samples)
+                hipLaunchKernelGGL(k_shade_whitted_a<true>, grid_for(bound), dim3(kBlock), 0, st, sc->d, lp, q, bound, n_dev, w.sq,
+                                   hits, w.hit_index, w.gq, w.sample);
+            else
+                hipLaunchKernelGGL(k_shade_whitted_a<false>, grid_for(bound), dim3(kBlock), 0, st, sc->d, lp, q, bound, n_dev, w.sq,
+                                   hits, w.hit_index, w.gq, w.sample);
+            HIP_TRY(hipGetLastError());
+            L.timer.end(&local.ms_shade);
+            // the number of hits stays on the device: the launches are sized for the most
+            // there can be and read the real number themselves
+            if (shadow_max > 0) {
+                L.trace_timer.begin();
+                r = launch_trace(sc, w, st, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, w.sq.limit, (uint32_t)shadow_max,
+                                 hits, bound, rd->flags, nullptr, w.sq.hit_depth, count_work);
+                if (r != RTX_OK) return r;
+                L.trace_timer.end(&local.ms_shadow);
+                local.traverse_launches++;
+            }
+            if (gather_max > 0) {
+                // the gather's nested rayTrace calls, reduced to what reaches the image: one
+                // closest-hit query each (their colour is discarded, :509-510)
+                L.trace_timer.begin();
+                r = launch_trace(sc, w, st, w.gq.ox, w.gq.oy, w.gq.oz, w.gq.dx, w.gq.dy, w.gq.dz, nullptr, (uint32_t)gather_max,
+                                 hits, bound, rd->flags, w.gq.hit_prim, w.gq.hit_depth, count_work);
+                if (r != RTX_OK) return r;
+                L.trace_timer.end(&local.ms_traverse);
+                local.traverse_launches++;
+            }
+            L.timer.begin();
+            if (lp.gather_samples)
+                hipLaunchKernelGGL(k_shade_whitted_b<true>, grid_for(bound), dim3(kBlock), 0, st, sc->d, lp, q, bound, n_dev, w.sq,
+                                   w.hit_index, w.gq, nq, next_len, w.sample);
+            else
+                hipLaunchKernelGGL(k_shade_whitted_b<false>, grid_for(bound), dim3(kBlock), 0, st, sc->d, lp, q, bound, n_dev, w.sq,
+                                   w.hit_index, w.gq, nq, next_len, w.sample);
+            HIP_TRY(hipGetLastError());
+            L.timer.end(&local.ms_shade);
+            shadow_mult = shadow_per_hit;
+            gather_mult = gather_per_hit;       // gather rays are layer+1 shootRay calls
+        }
+        hipLaunchKernelGGL(k_level_totals, dim3(1), dim3(1), 0, st, next_len, hits, w.work, shadow_mult, gather_mult,
+                           w.counts + 2 * ((level + 2) % 4));
+        HIP_TRY(hipGetLastError());
+        // rays are only spawned for layers up to max_depth (Raytracer.cpp:220, Desktop :456)
+        if (single_level || level >= rd->max_depth) { L.bound = 0; return RTX_OK; }
+        L.cur ^= 1;
+        L.level = level + 1;
+        if (sync_every_level || bound >= kLongLevel || level % 4 == 3) {
+            HIP_TRY(hipMemcpyAsync(w.host_counts, next_len, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            L.want_sync = true;
+        } else {
+            L.exact = false;        // without the mirror extension a level is never longer than the one before
+        }
+        return RTX_OK;
+    };
+    auto finish_chunk = [&](Lane& L) -> int {
+        L.timer.begin();
+        hipLaunchKernelGGL(k_resolve, grid_for(L.p.chunk_pixels), dim3(kBlock), 0, L.st, L.p, L.w->sample, accum);
+        HIP_TRY(hipGetLastError());
+        L.timer.end(&local.ms_resolve);
+        L.alive = false;
+        return RTX_OK;
+    };
+
+    for (uint32_t pass = rd->first_pass; pass < rd->first_pass + rd->passes; ++pass) {
+        uint64_t next_t0 = 0;
+        for (;;) {
+            // hand the next chunks to idle lanes
+            for (int k = 0; k < n_lanes; ++k) {
+                Lane& L = lanes[k];
+                if (L.alive || next_t0 >= padded_pixels) continue;
+                L.p.pass = pass;
+                L.p.chunk_t0 = (uint32_t)next_t0;
+                L.p.chunk_pixels = (uint32_t)std::min<uint64_t>(pixels_per_chunk, padded_pixels - next_t0);
+                next_t0 += L.p.chunk_pixels;
+                const size_t slots = (size_t)L.p.chunk_pixels * nn;
+                L.timer.begin();
+                hipLaunchKernelGGL(k_generate, grid_for(slots), dim3(kBlock), 0, L.st, L.p, L.w->q[0], L.w->sample, L.w->counts);
+                HIP_TRY(hipGetLastError());
+                L.timer.end(&local.ms_generate);
+                local.rays_primary += slots;
+                local.max_queue = std::max<uint32_t>(local.max_queue, (uint32_t)slots);
+                L.bound = (uint32_t)slots;      // one camera ray per sample slot
+                L.exact = true;                 // `bound` is the queue's length, not just a bound of it
+                L.cur = 0; L.level = 0; L.alive = true; L.want_sync = false;
+            }
+            bool any = false;
+            for (int k = 0; k < n_lanes; ++k) any = any || lanes[k].alive;
+            if (!any) break;
+            // a lane that waits for its queue length gets its next level enqueued before the
+            // other lane is waited for
+            for (int k = 0; k < n_lanes; ++k) {
+                Lane& L = lanes[k];
+                if (!L.alive) continue;
+                if (L.want_sync) {
+                    HIP_TRY(hipStreamSynchronize(L.st));
+                    L.want_sync = false;
+                    L.bound = L.w->host_counts[0];
+                    L.exact = true;
+                    if (L.bound > queue_cap) return fail(RTX_ERR_LIMIT, "ray queue overflow (%u > %zu)", L.bound, queue_cap);
+                    local.max_queue = std::max(local.max_queue, L.bound);
+                    if (L.bound == 0) { rc = finish_chunk(L); if (rc != RTX_OK) return rc; continue; }
+                }
+                rc = enqueue_level(L);
+                if (rc != RTX_OK) return rc;
+                if (L.bound == 0) { rc = finish_chunk(L); if (rc != RTX_OK) return rc; }
+            }
         }
     }
-    if (count_work) {
-        HIP_TRY(hipMemcpyAsync(w.host_work, w.work, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(w.host_work + 10, w.work + 10, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    for (int k = 0; k < n_lanes; ++k) {
+        Lane& L = lanes[k];
+        HIP_TRY(hipMemcpyAsync(L.w->host_work, L.w->work, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, L.st));
+        if (n_lanes > 1) {
+            HIP_TRY(hipEventRecord(sc->join_event[k], L.st));
+            HIP_TRY(hipStreamWaitEvent(user, sc->join_event[k], 0));
+        }
     }
-    HIP_TRY(hipMemcpyAsync(w.host_work + 8, w.work + 8, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(w.host_work + 12, w.work + 12, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    if (stats) HIP_TRY(hipEventRecord(ev1, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    local.rays_shadow += w.host_work[8];
-    local.rays_secondary += w.host_work[9] + w.host_work[12];
+    if (stats) HIP_TRY(hipEventRecord(ev1, user));
+    HIP_TRY(hipStreamSynchronize(user));
+    drain.armed = false;
+    unsigned long long work[16] = {0};
+    for (int k = 0; k < n_lanes; ++k)
+        for (int c = 0; c < 16; ++c) work[c] += lanes[k].w->host_work[c];
+    local.rays_shadow += work[8];
+    local.rays_secondary += work[9] + work[12];
     if (stats) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         local.ms_total = ms;
-        timer.collect();
-        trace_timer.collect();
+        for (int k = 0; k < n_lanes; ++k) { lanes[k].timer.collect(); lanes[k].trace_timer.collect(); }
         if (count_work) {
-            local.branch_visits = w.host_work[0]; local.leaf_visits = w.host_work[1]; local.aabb_tests = w.host_work[2];
-            local.triangle_tests = w.host_work[3]; local.sphere_tests = w.host_work[4]; local.hits_accepted = w.host_work[5];
-            local.content_tests = w.host_work[6]; local.fallback_rays = w.host_work[7];
-            local.wave_steps = w.host_work[10]; local.lane_steps = w.host_work[11];
+            local.branch_visits = work[0]; local.leaf_visits = work[1]; local.aabb_tests = work[2];
+            local.triangle_tests = work[3]; local.sphere_tests = work[4]; local.hits_accepted = work[5];
+            local.content_tests = work[6]; local.fallback_rays = work[7];
+            local.wave_steps = work[10]; local.lane_steps = work[11];
         }
         *stats = local;
     }

@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--sort-material", action="store_true", help="shade pathTrace levels in material order")
     ap.add_argument("--refill-lanes", action="store_true", help="BVH walk with finished lanes refilled from the queue")
+    ap.add_argument("--serial", action="store_true", help="one chunk at a time on the caller's stream (no two-lane overlap)")
+    ap.add_argument("--no-stage-times", action="store_true", help="no per-stage events (their gaps cost time on short frames)")
     ap.add_argument("--brief", action="store_true", help="print only config, rays/s, ms/frame and stage times")
     args = ap.parse_args()
     import torch
@@ -96,7 +98,8 @@ def main():
                 host_s += time.perf_counter() - th
             fb.zero_()
             rd = rd_of(1 + f)
-            rd.flags |= abi.FLAG_STAGE_TIMES | (abi.FLAG_SORT_MATERIAL if args.sort_material else 0)
+            rd.flags |= (0 if args.no_stage_times else abi.FLAG_STAGE_TIMES) | (abi.FLAG_SORT_MATERIAL if args.sort_material else 0)
+            rd.flags |= abi.FLAG_SERIAL_CHUNKS if args.serial else 0
             rd.flags |= abi.FLAG_REFILL_LANES if args.refill_lanes else 0
             st = ds.render_device(rd, fb.data_ptr())
             for k in rays:

@@ -4,7 +4,7 @@
     python tools/collect_profiles.py r01
 
 Expects what tools/profile_all.sh leaves behind: gpurun_out/kt_<walk>/ (kernel trace + stats of
-bench.py per walk), gpurun_out/kt_<walk>.json (the bench line printed under the profiler) and
+bench.py per walk, and kt_bvh-serial for the default walk with chunks one after the other), gpurun_out/kt_<walk>.json (the bench line printed under the profiler) and
 gpurun_out/pmc/summary.json (tools/profile_pmc.sh).  Also rewrites profiles/traffic.json, the HBM
 bytes per traversal launch that bench.py reports as roofline.traffic.
 """
@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main(tag):
     out = os.path.join(ROOT, "profiles")
     g = os.path.join(ROOT, "gpurun_out")
-    for walk in ("bvh", "kd-culled", "reference"):
+    for walk in ("bvh", "kd-culled", "reference", "bvh-serial"):
         stats = glob.glob(os.path.join(g, f"kt_{walk}", "*", "*kernel_stats.csv"))
         if stats:       # gpurun merges into what earlier calls left: take the newest
             shutil.copy(max(stats, key=os.path.getmtime), os.path.join(out, f"{tag}_kernel_stats_{walk}.csv"))

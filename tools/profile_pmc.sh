@@ -10,7 +10,7 @@ rm -rf "$OUT"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-frame16 ${BENCH_ARGS:-}"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-frame16 --no-serial-leg ${BENCH_ARGS:-}"
 run() {
     name=$1; shift
     timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$R/bench.py" $ARGS > "$OUT/$name.log" 2>&1
