@@ -760,7 +760,9 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     // one-workgroup kernels of one chunk overlap with the other's launches.  The budgets are for
     // both together; a tile that would fit one chunk is cut in two, and the number of chunks is
     // even with equal sizes.  Small tiles stay in one piece: halves would only make the tails longer.
-    const bool serial = (rd->flags & RTX_FLAG_SERIAL_CHUNKS) != 0 || padded_pixels * nn < (1u << 20);
+    uint64_t two_lane_min = 1u << 20;       // sample slots in the tile
+    if (const char* env = std::getenv("RTX_TWO_LANE_MIN")) { long v = std::atol(env); if (v >= 128) two_lane_min = (uint64_t)v; }
+    const bool serial = (rd->flags & RTX_FLAG_SERIAL_CHUNKS) != 0 || padded_pixels * nn < two_lane_min;
     if (!serial) {
         const uint64_t half = std::max<uint64_t>(64, pixels_per_chunk / 2 / 64 * 64);
         uint64_t n_chunks = (padded_pixels + half - 1) / half;
