@@ -193,7 +193,7 @@ def main():
                  + 45 * work["triangle_tests"] + 50 * work["hits_accepted"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.walk == "bvh" and not args.serial_chunks:      # measured for that walk, per half-frame launch
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
