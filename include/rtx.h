@@ -296,6 +296,19 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out);
 /* Run later work for this scene on `hip_stream` (a hipStream_t; NULL = default). */
 int rtx_scene_set_stream(rtx_scene* scene, void* hip_stream);
 
+/*
+ * Asynchronous calls for frame sequences.  The reference's frame loop (Raytracer.cpp:595-752)
+ * finishes one frame before it starts the next; a caller that keeps its buffers on the device
+ * does not need the host to wait in between.  With enabled != 0, rtx_render_device and
+ * rtx_present_device return once their work is queued on the scene's stream (a render call can
+ * still wait inside for a queue length it needs) and take no `stats`; rtx_scene_wait waits for
+ * everything queued so far and returns the statistics summed over the render calls since the
+ * last hand-out (ms_total stays 0).  The host-buffer calls rtx_render / rtx_present are refused on an
+ * asynchronous scene.  Switching back (enabled = 0) waits first.
+ */
+int rtx_scene_set_async(rtx_scene* scene, int enabled);
+int rtx_scene_wait(rtx_scene* scene, rtx_stats* totals);
+
 void rtx_scene_destroy(rtx_scene* scene);
 
 /*

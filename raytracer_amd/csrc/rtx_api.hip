@@ -114,6 +114,48 @@ size_t queue_bytes(size_t cap)
     return 2 * per_queue + 2 * al(cap * 4) + al(cap * 3 * 8) + 6 * al(cap * 8);
 }
 
+// Device time per stage: event pairs are recorded on the library stream without
+// waiting and read back once the stream has drained.
+struct StageTimer {
+    bool on;
+    hipStream_t stream;
+    struct Span { hipEvent_t a, b; double* acc; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t cur = nullptr;
+    StageTimer(bool on = false, hipStream_t s = nullptr) : on(on), stream(s) {}
+    ~StageTimer()
+    {
+        for (Span& sp : spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+        if (cur) (void)hipEventDestroy(cur);
+    }
+    void begin()
+    {
+        if (!on) return;
+        (void)hipEventCreate(&cur);
+        (void)hipEventRecord(cur, stream);
+    }
+    void end(double* acc)
+    {
+        if (!on || !cur) return;
+        hipEvent_t b = nullptr;
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(b, stream);
+        spans.push_back(Span{cur, b, acc});
+        cur = nullptr;
+    }
+    // call after the stream has been synchronised
+    void collect()
+    {
+        for (Span& sp : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) *sp.acc += ms;
+            (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);
+        }
+        spans.clear();
+    }
+};
+
 }  // namespace
 
 struct rtx_scene {
@@ -125,8 +167,16 @@ struct rtx_scene {
     Workspace ws[2];
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     hipEvent_t fork_event = nullptr, join_event[2] = {nullptr, nullptr};
+    // Statistics of the render calls since they were last handed out: with asynchronous calls
+    // (rtx_scene_set_async) that is several frames.  Ray totals by kind and the work counters
+    // accumulate on the device (Workspace::work), the rest here.
+    bool async = false;
+    rtx_stats pending;
+    StageTimer lane_timer[2], lane_trace_timer[2];
+    rtx_scene() { std::memset(&pending, 0, sizeof pending); }
     ~rtx_scene()
     {
+        for (int k = 0; k < 2; ++k) if (lane_stream[k]) (void)hipStreamSynchronize(lane_stream[k]);
         for (int k = 0; k < 2; ++k) {
             if (lane_stream[k]) (void)hipStreamDestroy(lane_stream[k]);
             if (join_event[k]) (void)hipEventDestroy(join_event[k]);
@@ -151,10 +201,12 @@ int ensure_workspace(Workspace& w, size_t cap, size_t shadow_cap, size_t gather_
     if (!w.counts) {
         HIP_TRY(hipMalloc(&w.counts, 8 * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&w.work, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(w.work, 0, 16 * sizeof(unsigned long long)));     // zero between collections
         HIP_TRY(hipMalloc(&w.bins, 2 * kBins * sizeof(uint32_t)));
         HIP_TRY(hipMemset(w.bins, 0, 2 * kBins * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc(&w.host_counts, 8 * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc(&w.host_work, 16 * sizeof(unsigned long long)));
+        std::memset(w.host_work, 0, 16 * sizeof(unsigned long long));
     }
     if (cap > w.capacity) {
         if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.capacity = 0; }
@@ -279,46 +331,6 @@ int validate_scene(const rtx_scene_desc* s, uint32_t* kd_depth)
 
 inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 inline dim3 trace_grid_for(size_t n) { return dim3((unsigned)((n + kTraceBlock - 1) / kTraceBlock)); }
-
-// Device time per stage: event pairs are recorded on the library stream without
-// waiting and read back once the stream has drained.
-struct StageTimer {
-    bool on;
-    hipStream_t stream;
-    struct Span { hipEvent_t a, b; double* acc; };
-    std::vector<Span> spans;
-    std::vector<hipEvent_t> pool;
-    hipEvent_t cur = nullptr;
-    StageTimer(bool on, hipStream_t s) : on(on), stream(s) {}
-    ~StageTimer()
-    {
-        for (Span& sp : spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
-        if (cur) (void)hipEventDestroy(cur);
-    }
-    void begin()
-    {
-        if (!on) return;
-        (void)hipEventCreate(&cur);
-        (void)hipEventRecord(cur, stream);
-    }
-    void end(double* acc)
-    {
-        if (!on || !cur) return;
-        hipEvent_t b = nullptr;
-        (void)hipEventCreate(&b);
-        (void)hipEventRecord(b, stream);
-        spans.push_back(Span{cur, b, acc});
-        cur = nullptr;
-    }
-    // call after the stream has been synchronised
-    void collect()
-    {
-        for (Span& sp : spans) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) *sp.acc += ms;
-        }
-    }
-};
 
 }  // namespace
 
@@ -642,6 +654,35 @@ int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* directi
 // limit == nullptr: closest hit; otherwise any hit with depth <= limit[i] (shadow rays).
 // seg == 0: the first min(n, *n_device) rays of a flat queue; seg != 0: a light-ray queue of
 // n = samples * seg entries, of which *n_device hits x samples are in use (see ray_place).
+// copy a lane's device counters to its pinned mirror and zero them for the next period
+static hipError_t enqueue_work_readback(Workspace& w, hipStream_t stream)
+{
+    hipError_t e = hipMemcpyAsync(w.host_work, w.work, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(w.work, 0, 16 * sizeof(unsigned long long), stream);
+    return e;
+}
+
+// after the streams have drained: everything since the statistics were last handed out
+static void hand_out_stats(rtx_scene* sc, rtx_stats* out)
+{
+    rtx_stats& t = sc->pending;
+    unsigned long long work[16] = {0};
+    for (int k = 0; k < 2; ++k) {
+        if (!sc->ws[k].host_work) continue;
+        for (int c = 0; c < 16; ++c) { work[c] += sc->ws[k].host_work[c]; sc->ws[k].host_work[c] = 0; }
+        sc->lane_timer[k].collect();
+        sc->lane_trace_timer[k].collect();
+    }
+    t.rays_shadow += work[8];
+    t.rays_secondary += work[9] + work[12];
+    t.branch_visits = work[0]; t.leaf_visits = work[1]; t.aabb_tests = work[2];
+    t.triangle_tests = work[3]; t.sphere_tests = work[4]; t.hits_accepted = work[5];
+    t.content_tests = work[6]; t.fallback_rays = work[7];
+    t.wave_steps = work[10]; t.lane_steps = work[11];
+    if (out) *out = t;
+    std::memset(&t, 0, sizeof t);
+}
+
 static int launch_trace(rtx_scene* sc, Workspace& ws, hipStream_t stream, const double* ox, const double* oy, const double* oz,
                         const double* dx, const double* dy, const double* dz, const double* limit, uint32_t n,
                         const uint32_t* n_device, uint32_t seg, uint32_t flags, int32_t* hit_prim, double* hit_depth, bool count)
@@ -790,8 +831,8 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     }
     hipStream_t user = sc->stream;
 
-    rtx_stats local;
-    std::memset(&local, 0, sizeof local);
+    if (sc->async && stats) return fail(RTX_ERR_INVALID, "asynchronous scene: statistics come from rtx_scene_wait");
+    rtx_stats& local = sc->pending;
     struct Events {
         hipEvent_t a = nullptr, b = nullptr;
         ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
@@ -799,6 +840,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     hipEvent_t& ev0 = ev.a;
     hipEvent_t& ev1 = ev.b;
     if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, user)); }
+    const bool keep_times = stats != nullptr || sc->async;
     if (n_lanes > 1) HIP_TRY(hipEventRecord(sc->fork_event, user));
 
     // rayTrace spawns nothing when no material refracts and the mirror extension is off
@@ -815,27 +857,27 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         Workspace* w = nullptr;
         hipStream_t st = nullptr;
         RenderParams p;
-        StageTimer timer, trace_timer;
+        StageTimer* timer_p = nullptr;
+        StageTimer* trace_timer_p = nullptr;
         uint32_t bound = 0, level = 0;
         bool exact = true, alive = false, want_sync = false;
         int cur = 0;
-        Lane(bool all, bool trace) : timer(all, nullptr), trace_timer(trace, nullptr) {}
     };
-    const bool time_all = stats != nullptr && (rd->flags & RTX_FLAG_STAGE_TIMES);
+    const bool time_all = keep_times && (rd->flags & RTX_FLAG_STAGE_TIMES);
     // the traversal launches alone (ms_traverse, ms_shadow): a third of the events of all stages
-    const bool time_trace = stats != nullptr && (rd->flags & (RTX_FLAG_STAGE_TIMES | RTX_FLAG_TRACE_TIMES));
-    Lane lanes[2] = {Lane(time_all, time_trace), Lane(time_all, time_trace)};
+    const bool time_trace = keep_times && (rd->flags & (RTX_FLAG_STAGE_TIMES | RTX_FLAG_TRACE_TIMES));
+    Lane lanes[2];
     for (int k = 0; k < n_lanes; ++k) {
         Lane& L = lanes[k];
         L.w = &sc->ws[k];
         L.st = n_lanes > 1 ? sc->lane_stream[k] : user;
-        L.timer.stream = L.trace_timer.stream = L.st;
+        L.timer_p = &sc->lane_timer[k];
+        L.trace_timer_p = &sc->lane_trace_timer[k];
+        L.timer_p->on = time_all; L.trace_timer_p->on = time_trace;
+        L.timer_p->stream = L.trace_timer_p->stream = L.st;
         L.p = p;
         L.p.queue_cap = (uint32_t)std::min<size_t>(L.w->capacity, 0xffffffffu);
         if (n_lanes > 1) HIP_TRY(hipStreamWaitEvent(L.st, sc->fork_event, 0));
-        // work counters and ray totals by kind (k_level_totals) are summed on the device per lane
-        // and read with the frame's end
-        HIP_TRY(hipMemsetAsync(L.w->work, 0, 16 * sizeof(unsigned long long), L.st));
     }
 
     // an error return leaves nothing of this frame running on the library's streams
@@ -857,18 +899,18 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         uint32_t* hits = len + 1;
         uint32_t* next_len = w.counts + 2 * ((level + 1) % 4);
         const uint32_t* n_dev = L.exact ? nullptr : len;
-        L.trace_timer.begin();
+        L.trace_timer_p->begin();
         // the shading kernels recompute the hit from its id: the depth is only kept for
         // the refilled walk's verification pass
         int r = launch_trace(sc, w, st, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, bound, n_dev, 0, rd->flags, q.hit_prim,
                              (rd->flags & RTX_FLAG_REFILL_LANES) ? q.hit_depth : nullptr, count_work);
         if (r != RTX_OK) return r;
-        L.trace_timer.end(&local.ms_traverse);
+        L.trace_timer_p->end(&local.ms_traverse);
         local.traverse_launches++;
         lp.layer = level;
         uint32_t shadow_mult = 0, gather_mult = 0;
         if (!whitted) {
-            L.timer.begin();
+            L.timer_p->begin();
             const uint32_t* perm = nullptr;
             if (rd->flags & RTX_FLAG_SORT_MATERIAL) {       // exact lengths here (sync_every_level)
                 hipLaunchKernelGGL(k_bin_count, grid_for(bound), dim3(kBlock), 0, st, sc->d, q.hit_prim, bound, w.bins);
@@ -878,7 +920,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
             }
             hipLaunchKernelGGL(k_shade_path, grid_for(bound), dim3(kBlock), 0, st, sc->d, lp, q, bound, n_dev, perm, nq, next_len, w.sample);
             HIP_TRY(hipGetLastError());
-            L.timer.end(&local.ms_shade);
+            L.timer_p->end(&local.ms_shade);
         } else {
             lp.gather_samples = gather_samples_at(level);
             lp.gather_traced = level + 1 <= rd->max_depth ? 1u : 0u;
@@ -888,7 +930,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
             const uint64_t shadow_max = (uint64_t)bound * shadow_per_hit;
             if (gather_max > w.gather_capacity) return fail(RTX_ERR_LIMIT, "gather queue overflow");
             if (shadow_max > w.shadow_capacity) return fail(RTX_ERR_LIMIT, "shadow queue overflow");
-            L.timer.begin();
+            L.timer_p->begin();
             if (lp.gather_samples)
                 hipLaunchKernelGGL(k_shade_whitted_a<true>, grid_for(bound), dim3(kBlock), 0, st, sc->d, lp, q, bound, n_dev, w.sq,
                                    hits, w.hit_index, w.gq, w.sample);
@@ -896,28 +938,28 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 hipLaunchKernelGGL(k_shade_whitted_a<false>, grid_for(bound), dim3(kBlock), 0, st, sc->d, lp, q, bound, n_dev, w.sq,
                                    hits, w.hit_index, w.gq, w.sample);
             HIP_TRY(hipGetLastError());
-            L.timer.end(&local.ms_shade);
+            L.timer_p->end(&local.ms_shade);
             // the number of hits stays on the device: the launches are sized for the most
             // there can be and read the real number themselves
             if (shadow_max > 0) {
-                L.trace_timer.begin();
+                L.trace_timer_p->begin();
                 r = launch_trace(sc, w, st, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, w.sq.limit, (uint32_t)shadow_max,
                                  hits, bound, rd->flags, nullptr, w.sq.hit_depth, count_work);
                 if (r != RTX_OK) return r;
-                L.trace_timer.end(&local.ms_shadow);
+                L.trace_timer_p->end(&local.ms_shadow);
                 local.traverse_launches++;
             }
             if (gather_max > 0) {
                 // the gather's nested rayTrace calls, reduced to what reaches the image: one
                 // closest-hit query each (their colour is discarded, :509-510)
-                L.trace_timer.begin();
+                L.trace_timer_p->begin();
                 r = launch_trace(sc, w, st, w.gq.ox, w.gq.oy, w.gq.oz, w.gq.dx, w.gq.dy, w.gq.dz, nullptr, (uint32_t)gather_max,
                                  hits, bound, rd->flags, w.gq.hit_prim, w.gq.hit_depth, count_work);
                 if (r != RTX_OK) return r;
-                L.trace_timer.end(&local.ms_traverse);
+                L.trace_timer_p->end(&local.ms_traverse);
                 local.traverse_launches++;
             }
-            L.timer.begin();
+            L.timer_p->begin();
             if (lp.gather_samples)
                 hipLaunchKernelGGL(k_shade_whitted_b<true>, grid_for(bound), dim3(kBlock), 0, st, sc->d, lp, q, bound, n_dev, w.sq,
                                    w.hit_index, w.gq, nq, next_len, w.sample);
@@ -925,7 +967,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 hipLaunchKernelGGL(k_shade_whitted_b<false>, grid_for(bound), dim3(kBlock), 0, st, sc->d, lp, q, bound, n_dev, w.sq,
                                    w.hit_index, w.gq, nq, next_len, w.sample);
             HIP_TRY(hipGetLastError());
-            L.timer.end(&local.ms_shade);
+            L.timer_p->end(&local.ms_shade);
             shadow_mult = shadow_per_hit;
             gather_mult = gather_per_hit;       // gather rays are layer+1 shootRay calls
         }
@@ -945,10 +987,10 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         return RTX_OK;
     };
     auto finish_chunk = [&](Lane& L) -> int {
-        L.timer.begin();
+        L.timer_p->begin();
         hipLaunchKernelGGL(k_resolve, grid_for(L.p.chunk_pixels), dim3(kBlock), 0, L.st, L.p, L.w->sample, accum);
         HIP_TRY(hipGetLastError());
-        L.timer.end(&local.ms_resolve);
+        L.timer_p->end(&local.ms_resolve);
         L.alive = false;
         return RTX_OK;
     };
@@ -965,10 +1007,10 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 L.p.chunk_pixels = (uint32_t)std::min<uint64_t>(pixels_per_chunk, padded_pixels - next_t0);
                 next_t0 += L.p.chunk_pixels;
                 const size_t slots = (size_t)L.p.chunk_pixels * nn;
-                L.timer.begin();
+                L.timer_p->begin();
                 hipLaunchKernelGGL(k_generate, grid_for(slots), dim3(kBlock), 0, L.st, L.p, L.w->q[0], L.w->sample, L.w->counts);
                 HIP_TRY(hipGetLastError());
-                L.timer.end(&local.ms_generate);
+                L.timer_p->end(&local.ms_generate);
                 local.rays_primary += slots;
                 local.max_queue = std::max<uint32_t>(local.max_queue, (uint32_t)slots);
                 L.bound = (uint32_t)slots;      // one camera ray per sample slot
@@ -1000,39 +1042,50 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     }
     for (int k = 0; k < n_lanes; ++k) {
         Lane& L = lanes[k];
-        HIP_TRY(hipMemcpyAsync(L.w->host_work, L.w->work, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, L.st));
+        if (!sc->async) HIP_TRY(enqueue_work_readback(*L.w, L.st));
         if (n_lanes > 1) {
             HIP_TRY(hipEventRecord(sc->join_event[k], L.st));
             HIP_TRY(hipStreamWaitEvent(user, sc->join_event[k], 0));
         }
     }
+    drain.armed = false;        // from here the caller's stream waits for the lanes
+    if (sc->async) return RTX_OK;
     if (stats) HIP_TRY(hipEventRecord(ev1, user));
     HIP_TRY(hipStreamSynchronize(user));
-    drain.armed = false;
-    unsigned long long work[16] = {0};
-    for (int k = 0; k < n_lanes; ++k)
-        for (int c = 0; c < 16; ++c) work[c] += lanes[k].w->host_work[c];
-    local.rays_shadow += work[8];
-    local.rays_secondary += work[9] + work[12];
     if (stats) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         local.ms_total = ms;
-        for (int k = 0; k < n_lanes; ++k) { lanes[k].timer.collect(); lanes[k].trace_timer.collect(); }
-        if (count_work) {
-            local.branch_visits = work[0]; local.leaf_visits = work[1]; local.aabb_tests = work[2];
-            local.triangle_tests = work[3]; local.sphere_tests = work[4]; local.hits_accepted = work[5];
-            local.content_tests = work[6]; local.fallback_rays = work[7];
-            local.wave_steps = work[10]; local.lane_steps = work[11];
-        }
-        *stats = local;
     }
+    hand_out_stats(sc, stats);
+    return RTX_OK;
+}
+
+int rtx_scene_set_async(rtx_scene* sc, int enabled)
+{
+    if (!sc) return fail(RTX_ERR_INVALID, "null scene");
+    if (sc->async && !enabled) {
+        int rc = rtx_scene_wait(sc, nullptr);
+        if (rc != RTX_OK) return rc;
+    }
+    sc->async = enabled != 0;
+    return RTX_OK;
+}
+
+int rtx_scene_wait(rtx_scene* sc, rtx_stats* totals)
+{
+    if (!sc) return fail(RTX_ERR_INVALID, "null scene");
+    for (int k = 0; k < 2; ++k)
+        if (sc->ws[k].work) HIP_TRY(enqueue_work_readback(sc->ws[k], sc->stream));    // the lanes have been joined to it
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    hand_out_stats(sc, totals);
     return RTX_OK;
 }
 
 int rtx_render(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rtx_stats* stats)
 {
     if (!sc || !rd || !accum) return fail(RTX_ERR_INVALID, "null argument");
+    if (sc->async) return fail(RTX_ERR_INVALID, "asynchronous scene: use rtx_render_device");
     size_t bytes = (size_t)rd->tile_w * rd->tile_h * 3 * sizeof(float);
     if (bytes == 0) return fail(RTX_ERR_INVALID, "empty tile");
     float* d_accum = nullptr;
@@ -1059,7 +1112,7 @@ int rtx_present_device(rtx_scene* sc, const float* accum, uint32_t width, uint32
     hipLaunchKernelGGL(k_present, grid_for(total), dim3(kBlock), 0, sc->stream, accum, width, height, (float)passes, tonemap,
                        flip ? 1u : 0u, rgb8);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(sc->stream));
+    if (!sc->async) HIP_TRY(hipStreamSynchronize(sc->stream));
     return RTX_OK;
 }
 
@@ -1067,6 +1120,7 @@ int rtx_present(rtx_scene* sc, const float* accum, uint32_t width, uint32_t heig
                 int flip, uint8_t* rgb8)
 {
     if (!sc || !accum || !rgb8) return fail(RTX_ERR_INVALID, "null argument");
+    if (sc->async) return fail(RTX_ERR_INVALID, "asynchronous scene: use rtx_present_device");
     size_t total = (size_t)width * height * 3;
     if (total == 0) return fail(RTX_ERR_INVALID, "bad frame size");
     float* d_accum = nullptr;

@@ -20,6 +20,7 @@ PD = C.POINTER(C.c_double)
 
 # every symbol include/rtx.h declares
 EXPORTS = ["rtx_init", "rtx_device_count", "rtx_scene_create", "rtx_scene_set_stream", "rtx_scene_destroy",
+           "rtx_scene_set_async", "rtx_scene_wait",
            "rtx_trace_closest", "rtx_render", "rtx_render_device", "rtx_present", "rtx_present_device", "rtx_uniform",
            "rtx_last_error"]
 
@@ -41,6 +42,8 @@ def lib():
     L.rtx_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_void_p)]
     L.rtx_scene_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.rtx_scene_destroy.argtypes = [C.c_void_p]
+    L.rtx_scene_set_async.argtypes = [C.c_void_p, C.c_int]
+    L.rtx_scene_wait.argtypes = [C.c_void_p, C.POINTER(abi.Stats)]
     L.rtx_scene_destroy.restype = None
     L.rtx_trace_closest.argtypes = [
         C.c_void_p, PD, PD, C.c_size_t, C.c_uint32, C.POINTER(C.c_int32), PD, PD, PD, PD, PD,
@@ -78,8 +81,21 @@ class DeviceScene:
         h = C.c_void_p()
         _check(self._L.rtx_scene_create(C.byref(desc), C.byref(h)))
         self._h = h
+        self._async = False
         if stream is not None:
             _check(self._L.rtx_scene_set_stream(self._h, C.c_void_p(stream)))
+
+    def set_async(self, enabled=True):
+        """rtx_scene_set_async: render_device / present_device return once their work is queued;
+        wait() returns the statistics of the frames since the last hand-out."""
+        _check(self._L.rtx_scene_set_async(self._h, int(bool(enabled))))
+        self._async = bool(enabled)
+
+    def wait(self):
+        """rtx_scene_wait: wait for everything queued on the scene's stream; summed Stats."""
+        stats = abi.Stats()
+        _check(self._L.rtx_scene_wait(self._h, C.byref(stats)))
+        return stats
 
     def close(self):
         if getattr(self, "_h", None):
@@ -135,12 +151,15 @@ class DeviceScene:
         return accum, stats
 
     def render_device(self, rd, accum_ptr, want_stats=True):
-        """rtx_render_device on device memory (e.g. a torch tensor's data_ptr())."""
+        """rtx_render_device on device memory (e.g. a torch tensor's data_ptr()).  On an
+        asynchronous scene nothing is returned: the statistics come from wait()."""
+        if self._async:
+            _check(self._L.rtx_render_device(self._h, C.byref(rd), C.c_void_p(accum_ptr), None))
+            return None
         stats = abi.Stats()
         _check(self._L.rtx_render_device(self._h, C.byref(rd), C.c_void_p(accum_ptr),
                                          C.byref(stats) if want_stats else None))
         return stats
-
 
     def present(self, accum, passes=1, tonemap=abi.TONEMAP_CBRT, flip=True):
         """rtx_present: [H, W, 3] float accumulation buffer (row 0 = bottom) -> [H, W, 3] uint8 sRGB."""
