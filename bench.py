@@ -9,7 +9,10 @@ tree, Whitted integrator with one DirectionalLight: primary + hard shadow rays,
 1920x1080, 1 sample per pixel.  A step is one frame of an orbiting camera
 (t = frame/30): rtx_render_device into a float framebuffer resident in HBM,
 then rtx_present_device (what the reference does between drawBuffer and the PNG:
-8-bit sRGB, flipped).  With N > 1 ranks every rank renders and presents its own
+8-bit sRGB, flipped).  The frames of the sequence are independent, so a rank keeps
+--in-flight of them (default 4) queued on as many streams, each through its own handle
+on the one device copy of the scene (rtx_scene_clone) with its own framebuffers: the
+tail of one frame's launches is filled by the next frames' kernels.  With N > 1 ranks every rank renders and presents its own
 frame of the sequence (frames are independent given the read-only scene) and
 the N presented frames are gathered to rank 0 with RCCL inside the timed
 region, as a frame driver that writes the PNGs on rank 0 needs them; per-GPU
@@ -42,8 +45,11 @@ def frame_time(step, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="frames of the sequence queued at once, each on a stream of its own (1: one frame at a time, "
+                         "its two half-frame chunks on the library's two streams)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,40 +97,49 @@ def main():
     desc = scene.frame(0.0)
     kd = scene.kd_stats()
     kflags = {"bvh": 0, "kd-culled": abi.FLAG_KD_CULLED, "reference": abi.FLAG_REFERENCE_ORDER}[args.walk]
-    if args.serial_chunks:
+    F = max(1, args.in_flight)
+    if args.serial_chunks or F > 1:     # frames in flight overlap each other; their chunks need not
         kflags |= abi.FLAG_SERIAL_CHUNKS
     stream = torch.cuda.current_stream().cuda_stream
     ds = device.DeviceScene(desc, stream=stream)
+    # handle k renders the frames with step % F == k on stream k
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(F - 1)]
+    handles = [ds] + [ds.clone(stream=st.cuda_stream) for st in streams[1:]]
 
     def rd_for(step, flags):
         cam = scenes.orbit_camera(frame_time(step, rank, world))
         return scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=1, max_depth=3, bias=1e-2,
                                   clear=(0.21, 0.78, 0.95), flags=flags | kflags)
 
-    # two presented frames: the gather of frame k (RCCL's own stream) overlaps the render of frame k+1
+    # per handle: a float framebuffer and two presented frames (the gather of one, on RCCL's own
+    # stream, overlaps the handle's next render)
     fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    shown = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    fbs = [fb] + [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(F - 1)]
+    shown = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2 * F)]
     gathered = [[torch.zeros((H, W, 3), dtype=torch.uint8, device=comm_dev) for _ in range(world)]
-                if (world > 1 and rank == 0) else None for _ in range(2)]
-    pending = [None, None]
+                if (world > 1 and rank == 0) else None for _ in range(2 * F)]
+    pending = [None] * (2 * F)
 
     def step_fn(step, flags):
-        k = step & 1
-        if pending[k] is not None:
-            pending[k].wait()
-            pending[k] = None
-        fb.zero_()
-        st = ds.render_device(rd_for(step, flags), fb.data_ptr())
-        ds.present_device(fb.data_ptr(), W, H, shown[k].data_ptr(), passes=1, tonemap=abi.TONEMAP_NONE, flip=True)
-        if world > 1:
-            src = shown[k] if backend == "nccl" else shown[k].cpu()
-            pending[k] = dist.gather(src, gathered[k], dst=0, async_op=True)
+        h = step % F
+        k = 2 * h + (step // F) % 2
+        with torch.cuda.stream(streams[h]):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+            fbs[h].zero_()
+            st = handles[h].render_device(rd_for(step, flags), fbs[h].data_ptr())
+            handles[h].present_device(fbs[h].data_ptr(), W, H, shown[k].data_ptr(), passes=1, tonemap=abi.TONEMAP_NONE, flip=True)
+            if world > 1:
+                src = shown[k] if backend == "nccl" else shown[k].cpu()
+                pending[k] = dist.gather(src, gathered[k], dst=0, async_op=True)
         return st
 
     def drain():
-        for k in range(2):
+        for k in range(2 * F):
             if pending[k] is not None:
-                pending[k].wait()
+                with torch.cuda.stream(streams[k // 2]):
+                    pending[k].wait()
                 pending[k] = None
 
     # ---- algorithmic bytes of exactly the timed frames (untimed, counting kernels) ----
@@ -139,11 +154,13 @@ def main():
 
     # The frames of the sequence are queued without the host waiting in between (the buffers stay
     # on the device and the stream orders render -> present -> gather); one wait ends the region.
-    ds.set_async(True)
+    for h in handles:
+        h.set_async(True)
     for s in range(args.warmup):
         step_fn(s, abi.FLAG_TRACE_TIMES)
     drain()
-    ds.wait()
+    for h in handles:
+        h.wait()
 
     def sync():
         if world > 1:
@@ -155,16 +172,19 @@ def main():
     for s in range(args.steps):
         step_fn(args.warmup + s, abi.FLAG_TRACE_TIMES)      # HIP events around the traversal launches only
     drain()
-    st = ds.wait()              # totals over the K frames
+    totals = [h.wait() for h in handles]        # statistics summed over each handle's frames
     sync()
     elapsed = time.perf_counter() - t0
-    rays, launches, ms_trav = st.rays, st.traverse_launches, st.ms_traverse + st.ms_shadow
-    ds.set_async(False)
+    rays = sum(st.rays for st in totals)
+    launches = sum(st.traverse_launches for st in totals)
+    ms_trav = sum(st.ms_traverse + st.ms_shadow for st in totals)
+    for h in handles:
+        h.set_async(False)
 
     # The same frames once more, untimed, with the two chunks one after the other: every traversal
     # launch then has the machine to itself, which is what a per-launch bandwidth should be read on.
     serial = None
-    if not args.serial_chunks and not args.no_serial_leg:
+    if not (args.serial_chunks and F == 1) and not args.no_serial_leg:
         s_ms, s_launches = 0.0, 0
         for s in range(args.steps):
             st = ds.render_device(rd_for(args.warmup + s, abi.FLAG_TRACE_TIMES | abi.FLAG_SERIAL_CHUNKS), fb.data_ptr())
@@ -195,7 +215,7 @@ def main():
                  + 45 * work["triangle_tests"] + 50 * work["hits_accepted"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.walk == "bvh" and not args.serial_chunks:      # measured for that walk, per half-frame launch
+        if os.path.exists(tpath) and args.walk == "bvh" and (kflags & abi.FLAG_SERIAL_CHUNKS):    # measured for that walk, per whole-frame launch
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -221,6 +241,7 @@ def main():
                 "parallelism": (f"frames x{world}, {'RCCL' if backend == 'nccl' else backend} gather of the presented "
                                 "RGB8 frames to rank 0" if world > 1 else "single GPU"),
                 "step": "render (float framebuffer in HBM) + present (8-bit sRGB, flipped); frames queued asynchronously, one wait at the end",
+                "frames_in_flight": F,
             },
             "rays_per_frame": total_rays / frames,
             "ms_per_frame": round(elapsed / frames * 1e3, 4),       # sequence throughput: all ranks' frames
@@ -232,7 +253,7 @@ def main():
                 "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
                 # two half-frame chunks run on two streams: a launch shares the machine with the other
                 # chunk's kernels, so its duration (and `achieved`) is that of a kernel on part of the GPU
-                "launches_overlap": not args.serial_chunks,
+                "launches_overlap": F > 1 or not args.serial_chunks,
                 "serial": serial,
                 "fp64_valu_tflops": round(flops / (ms_trav / 1e3) / 1e12, 3) if ms_trav > 0 else None,
                 "fp64_valu_frac": round(flops / (ms_trav / 1e3) / 1e12 / FP64_PEAK_TFLOPS, 4) if ms_trav > 0 else None,
@@ -240,6 +261,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(desc, lambda f: rd_for(f, 0), args.warmup)
+    for h in handles[1:]:
+        h.close()
     ds.close()
     if not args.no_frame16:
         # second half of the headline metric: ms per 1080p 16-spp frame, one frame split into
@@ -264,17 +287,34 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
     scene, _ = scenes.mesh_scene(ggx=True, square_light=True)
     desc = scene.frame(0.0)
     ds = device.DeviceScene(desc, stream=stream)
+    # the rank's four bands are queued on four streams, each through its own handle on the scene
+    B = int(os.environ.get("BENCH_BAND_STREAMS", "4"))
+    streams = [torch.cuda.Stream() for _ in range(B)]
+    handles = [ds.clone(stream=st.cuda_stream) for st in streams]
+    for h in handles:
+        h.set_async(True)
     rays = [0]
+    fl = abi.FLAG_SERIAL_CHUNKS if os.environ.get("BENCH_BAND_SERIAL", "1") == "1" else 0
 
     def one_frame(f):
         cam = scenes.orbit_camera(f / 30.0)
+        queued = [0]
+        start = torch.cuda.Event()
+        start.record()              # the zeroed band buffers
 
         def render_rect(x0, y0, w, h, out):
             rd = scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=4, light_n=2, max_depth=3,
-                                    bias=1e-2, frame=f, tile=(x0, y0, w, h))
-            rays[0] += ds.render_device(rd, out.data_ptr()).rays
+                                    bias=1e-2, frame=f, tile=(x0, y0, w, h), flags=fl)
+            k = queued[0] % B
+            queued[0] += 1
+            streams[k].wait_event(start)
+            handles[k].render_device(rd, out.data_ptr())
+
+        def after_bands():
+            for k in range(B):
+                rays[0] += handles[k].wait().rays
         # four interleaved bands of equal height per rank
-        return rdist.render_frame_bands(render_rect, W, H, dev, bands_per_rank=4,
+        return rdist.render_frame_bands(render_rect, W, H, dev, bands_per_rank=4, after_bands=after_bands,
                                         comm_device=None if comm_dev == dev else comm_dev)
 
     def sync():
@@ -296,9 +336,12 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt = mx[0].item()
+    for h in handles:
+        h.close()
     ds.close()
     return {"workload": "configs[3]: GGX-parameter mesh, texture + checker floor, SquareLight 2x2 samples, 1080p 16 spp, "
-                        f"whitted; one frame in {4 * world} interleaved bands of equal height, four per rank",
+                        f"whitted; one frame in {4 * world} interleaved bands of equal height, four per rank, "
+                        f"queued on {B} streams",
             "ms_per_frame": round(dt / frames * 1e3, 3), "Mrays_per_s": round(tt[1].item() / dt / 1e6, 1),
             "frames": frames, "n_gpus": world, "scaling": "strong"}
 

@@ -309,6 +309,14 @@ int rtx_scene_set_stream(rtx_scene* scene, void* hip_stream);
 int rtx_scene_set_async(rtx_scene* scene, int enabled);
 int rtx_scene_wait(rtx_scene* scene, rtx_stats* totals);
 
+/*
+ * Another handle on the same device copy of the scene, with a stream, queues and statistics of
+ * its own (no counterpart in the reference, which has one frame in flight).  Frames rendered
+ * through different handles on different streams run concurrently: the tail of one frame's
+ * launches is filled by the next frame's.  The device arrays are freed with the last handle.
+ */
+int rtx_scene_clone(const rtx_scene* scene, rtx_scene** out);
+
 void rtx_scene_destroy(rtx_scene* scene);
 
 /*

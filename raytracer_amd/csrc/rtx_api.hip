@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <utility>
 #include <string>
 #include <vector>
@@ -160,7 +161,7 @@ struct StageTimer {
 
 struct rtx_scene {
     DScene d;
-    DeviceBuffers buffers;
+    std::shared_ptr<DeviceBuffers> buffers;     // the scene arrays in HBM; shared by the handles rtx_scene_clone makes
     // Two lanes: a frame's chunks are rendered two at a time on the library's own streams, so that
     // while one chunk's launch drains (a traversal launch ends in a tail of a few long rays) the
     // other chunk's kernels fill the machine.  A lane owns its queues and counters.
@@ -546,7 +547,8 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
         for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(b.bmin[k]), std::fabs(b.bmax[k])));
     d.scene_scale = scale;
 
-    DeviceBuffers& B = sc->buffers;
+    sc->buffers = std::make_shared<DeviceBuffers>();
+    DeviceBuffers& B = *sc->buffers;
     hipError_t e = hipSuccess;
     auto up = [&](auto host, size_t count, auto out_ptr) { if (e == hipSuccess) e = B.upload(host, count, out_ptr); };
     up(branches.data(), branches.size(), &d.branches);
@@ -589,6 +591,24 @@ int rtx_scene_set_stream(rtx_scene* sc, void* hip_stream)
 {
     if (!sc) return fail(RTX_ERR_INVALID, "null scene");
     sc->stream = static_cast<hipStream_t>(hip_stream);
+    return RTX_OK;
+}
+
+int rtx_scene_clone(const rtx_scene* sc, rtx_scene** out)
+{
+    if (!sc || !out) return fail(RTX_ERR_INVALID, "null argument");
+    rtx_scene* c = new rtx_scene();
+    c->d = sc->d;
+    c->buffers = sc->buffers;
+    c->device = sc->device;
+    c->kd_depth = sc->kd_depth;
+    c->bvh_depth = sc->bvh_depth;
+    c->may_refract = sc->may_refract;
+    c->light_multisample = sc->light_multisample;
+    c->compute_units = sc->compute_units;
+    c->refill_range = sc->refill_range;
+    c->refill_at = sc->refill_at;
+    *out = c;
     return RTX_OK;
 }
 

@@ -20,7 +20,7 @@ PD = C.POINTER(C.c_double)
 
 # every symbol include/rtx.h declares
 EXPORTS = ["rtx_init", "rtx_device_count", "rtx_scene_create", "rtx_scene_set_stream", "rtx_scene_destroy",
-           "rtx_scene_set_async", "rtx_scene_wait",
+           "rtx_scene_set_async", "rtx_scene_wait", "rtx_scene_clone",
            "rtx_trace_closest", "rtx_render", "rtx_render_device", "rtx_present", "rtx_present_device", "rtx_uniform",
            "rtx_last_error"]
 
@@ -43,6 +43,7 @@ def lib():
     L.rtx_scene_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.rtx_scene_destroy.argtypes = [C.c_void_p]
     L.rtx_scene_set_async.argtypes = [C.c_void_p, C.c_int]
+    L.rtx_scene_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.rtx_scene_wait.argtypes = [C.c_void_p, C.POINTER(abi.Stats)]
     L.rtx_scene_destroy.restype = None
     L.rtx_trace_closest.argtypes = [
@@ -76,14 +77,22 @@ def device_count():
 class DeviceScene:
     """One frame's scene resident in HBM (rtx_scene_create .. rtx_scene_destroy)."""
 
-    def __init__(self, desc, stream=None):
+    def __init__(self, desc, stream=None, _clone_of=None):
         self._L = lib()
         h = C.c_void_p()
-        _check(self._L.rtx_scene_create(C.byref(desc), C.byref(h)))
+        if _clone_of is not None:
+            _check(self._L.rtx_scene_clone(_clone_of._h, C.byref(h)))
+        else:
+            _check(self._L.rtx_scene_create(C.byref(desc), C.byref(h)))
         self._h = h
         self._async = False
         if stream is not None:
             _check(self._L.rtx_scene_set_stream(self._h, C.c_void_p(stream)))
+
+    def clone(self, stream=None):
+        """rtx_scene_clone: a handle with its own stream, queues and statistics on the same
+        device copy of the scene (frames in flight on several streams)."""
+        return DeviceScene(None, stream=stream, _clone_of=self)
 
     def set_async(self, enabled=True):
         """rtx_scene_set_async: render_device / present_device return once their work is queued;

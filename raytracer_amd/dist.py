@@ -49,7 +49,7 @@ def _gather_to_rank0(local, world, rank, group=None):
 
 
 def render_frame_bands(render_rect, width, height, device, band_rows=64, group=None, comm_device=None,
-                       bands_per_rank=None):
+                       bands_per_rank=None, after_bands=None):
     """Render one frame cooperatively.
 
     render_rect(x0, y0, w, h, out) must accumulate the rectangle's float32 RGB into `out`
@@ -57,6 +57,9 @@ def render_frame_bands(render_rect, width, height, device, band_rows=64, group=N
     [height, width, 3] frame on rank 0 and None on the other ranks.  `comm_device` is where
     the gather runs when the process group cannot move `device` tensors (gloo with GPU
     framebuffers); the frame is then returned there.  Bands: see band_edges().
+    render_rect may only queue its work (asynchronous scene handles on several streams);
+    `after_bands()` is then called once all of this rank's bands are queued and must make the
+    current stream wait for them.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -69,6 +72,8 @@ def render_frame_bands(render_rect, width, height, device, band_rows=64, group=N
     mine = band_rects(width, height, world, rank, band_rows, bands_per_rank)
     for k, (x0, y0, w, h) in enumerate(mine):
         render_rect(x0, y0, w, h, packed[k, :h])
+    if after_bands is not None:
+        after_bands()
     if comm_device is not None and torch.device(comm_device) != packed.device:
         packed = packed.to(comm_device)
     parts = _gather_to_rank0(packed, world, rank, group)

@@ -55,3 +55,36 @@ def test_queued_frames_equal_waited_frames(gpu, kind):
         ds.set_async(False)
         img, st1 = ds.render(scenes.render_desc(64, 48, camera=cam, **kw))
         assert st1.rays_primary == 64 * 48 * kw["n"] ** 2 and np.isfinite(img).all()
+
+
+def test_frames_in_flight_on_cloned_handles(gpu):
+    """rtx_scene_clone: handles on one device copy of the scene, each with its own stream, render
+    frames concurrently; images equal those of the original handle one call at a time, and the
+    clones outlive the handle they were made from."""
+    import torch
+    scene, cam = scenes.mesh_scene(slices=60, stacks=30, ggx=True, square_light=True)
+    desc = scene.frame(0.0)
+    W, H, frames = 640, 360, 6
+    kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=2, light_n=2, max_depth=3, bias=1e-2)
+    rds = [scenes.render_desc(W, H, camera=cam, seed=3, frame=f, **kw) for f in range(frames)]
+    ds = gpu.DeviceScene(desc)
+    want, rays = [], 0
+    for rd in rds:
+        img, st = ds.render(rd)
+        want.append(img)
+        rays += st.rays
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    clones = [ds.clone(stream=s.cuda_stream) for s in streams]
+    ds.close()                                  # the device arrays stay while a clone lives
+    for c in clones:
+        c.set_async(True)
+    fbs = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in rds]
+    torch.cuda.synchronize()
+    for f, rd in enumerate(rds):
+        clones[f % 3].render_device(rd, fbs[f].data_ptr())
+    got_rays = sum(c.wait().rays for c in clones)
+    assert got_rays == rays
+    for a, fb in zip(want, fbs):
+        assert np.array_equal(a, fb.cpu().numpy())
+    for c in clones:
+        c.close()
