@@ -520,10 +520,13 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     bool tie = false;
     d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     const double abs_margin = 1e-9 * (s.scene_scale + __builtin_fmax(fabs(o.x), __builtin_fmax(fabs(o.y), fabs(o.z))));
-    // closest hit: squared distance bound; any hit: the light distance itself, compared with
-    // the largest per-axis gap
-    double bound2 = kInf;
-    if constexpr (ANYHIT) bound2 = limit * (1.0 + 1e-7) + abs_margin;
+    // A child is skipped when the ray enters its box beyond `bound`: the best depth so far
+    // (closest hit) or the light distance (any hit), with a margin.  Directions are unit
+    // vectors, so the ray parameter is the distance from the origin up to rounding, every hit
+    // point the reference computes lies on the ray and in its shape's box up to rounding, and
+    // the margin (1e-7 relative + 1e-9 of the scene) is far above those errors.
+    double bound = kInf;
+    if constexpr (ANYHIT) bound = limit * (1.0 + 1e-7) + abs_margin;
     int sp = 0;
     int32_t node = s.bvh_root;
     bool done = false;
@@ -534,12 +537,12 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
             const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
             const d3 lb0 = mk(n0.x, n0.y, n0.z), lb1 = mk(n0.w, n1.x, n1.y);
             const d3 rb0 = mk(n1.z, n1.w, n2.x), rb1 = mk(n2.y, n2.z, n2.w);
-            double lmin, lmax, rmin, rmax, lgap, rgap;
-            slab_and_gap<ANYHIT>(lb0, lb1, o, inv, lmin, lmax, lgap);
-            slab_and_gap<ANYHIT>(rb0, rb1, o, inv, rmin, rmax, rgap);
+            double lmin, lmax, rmin, rmax;
+            slab_finite(lb0, lb1, o, inv, lmin, lmax);
+            slab_finite(rb0, rb1, o, inv, rmin, rmax);
             if constexpr (COUNT) w.content += 2;
-            bool hl = lmin <= lmax && lmax >= 0.0 && !(lgap > bound2);
-            bool hr = rmin <= rmax && rmax >= 0.0 && !(rgap > bound2);
+            bool hl = lmin <= lmax && lmax >= 0.0 && !(lmin > bound);
+            bool hr = rmin <= rmax && rmax >= 0.0 && !(rmin > bound);
             int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
             if (hl && hr) {
                 bool left_first = lmin <= rmin;
@@ -586,8 +589,7 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 } else if (depth < best_depth) {
                     if constexpr (COUNT) w.accepted++;
                     best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; tie = false;
-                    double bd = best_depth * (1.0 + 1e-7) + abs_margin;
-                    bound2 = bd * bd;
+                    bound = best_depth * (1.0 + 1e-7) + abs_margin;
                 } else if ((int32_t)rp != best_prim) {
                     tie = true;
                 }
@@ -840,12 +842,12 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
                 const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
                 const d3 lb0 = mk(n0.x, n0.y, n0.z), lb1 = mk(n0.w, n1.x, n1.y);
                 const d3 rb0 = mk(n1.z, n1.w, n2.x), rb1 = mk(n2.y, n2.z, n2.w);
-                double lmin, lmax, rmin, rmax, lgap, rgap;
-                slab_and_gap<ANYHIT>(lb0, lb1, o, inv, lmin, lmax, lgap);
-                slab_and_gap<ANYHIT>(rb0, rb1, o, inv, rmin, rmax, rgap);
+                double lmin, lmax, rmin, rmax;
+                slab_finite(lb0, lb1, o, inv, lmin, lmax);
+                slab_finite(rb0, rb1, o, inv, rmin, rmax);
                 if constexpr (COUNT) w.content += 2;
-                const bool hl = lmin <= lmax && lmax >= 0.0 && !(lgap > bound2);
-                const bool hr = rmin <= rmax && rmax >= 0.0 && !(rgap > bound2);
+                const bool hl = lmin <= lmax && lmax >= 0.0 && !(lmin > bound2);
+                const bool hr = rmin <= rmax && rmax >= 0.0 && !(rmin > bound2);
                 const int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
                 if (hl && hr) {
                     const bool left_first = lmin <= rmin;
@@ -893,8 +895,7 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
                     } else if (depth < best_depth) {
                         if constexpr (COUNT) w.accepted++;
                         best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; tie = false;
-                        const double bd = best_depth * (1.0 + 1e-7) + abs_margin;
-                        bound2 = bd * bd;
+                        bound2 = best_depth * (1.0 + 1e-7) + abs_margin;
                     } else if ((int32_t)rp != best_prim) {
                         tie = true;
                     }
