@@ -998,7 +998,9 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         if (single_level || level >= rd->max_depth) { L.bound = 0; return RTX_OK; }
         L.cur ^= 1;
         L.level = level + 1;
-        if (sync_every_level || bound >= kLongLevel || level % 4 == 3) {
+        // an asynchronous scene never waits for a short level: other frames are in flight and the
+        // launches of a level that turns out empty cost less than holding up the host
+        if (sync_every_level || bound >= kLongLevel || (level % 4 == 3 && !sc->async)) {
             HIP_TRY(hipMemcpyAsync(w.host_counts, next_len, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             L.want_sync = true;
         } else {

@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--refill-lanes", action="store_true", help="BVH walk with finished lanes refilled from the queue")
     ap.add_argument("--serial", action="store_true", help="one chunk at a time on the caller's stream (no two-lane overlap)")
     ap.add_argument("--no-stage-times", action="store_true", help="no per-stage events (their gaps cost time on short frames)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="also time the frames queued asynchronously on this many streams (handles cloned from the scene)")
     ap.add_argument("--brief", action="store_true", help="print only config, rays/s, ms/frame and stage times")
     args = ap.parse_args()
     import torch
@@ -118,8 +120,39 @@ def main():
                "host_rebuild_s_per_frame": round(host_s / frames, 3) if animated else None,
                "finite": bool(torch.isfinite(fb).all().item())}
         out["refill_lanes"] = args.refill_lanes
+        if args.in_flight > 1 and not animated:
+            # the same frames queued without waiting, frame f through handle f mod F on stream f mod F
+            F = args.in_flight
+            streams = [torch.cuda.Stream() for _ in range(F)]
+            clones = [ds.clone(stream=st_.cuda_stream) for st_ in streams]
+            fbs = [torch.zeros_like(fb) for _ in range(F)]
+            for c in clones:
+                c.set_async(True)
+
+            def queue(f):
+                k = f % F
+                with torch.cuda.stream(streams[k]):
+                    fbs[k].zero_()
+                    rd = rd_of(1 + f)
+                    rd.flags |= abi.FLAG_SERIAL_CHUNKS
+                    clones[k].render_device(rd, fbs[k].data_ptr())
+            for f in range(F):
+                queue(f)
+            for c in clones:
+                c.wait()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for f in range(frames):
+                queue(f)
+            q_rays = sum(c.wait().rays for c in clones)
+            torch.cuda.synchronize()
+            dtq = time.perf_counter() - t0
+            out["in_flight"] = {"frames_in_flight": F, "ms_per_frame": round(dtq / frames * 1e3, 3),
+                                "Mrays_per_s": round(q_rays / dtq / 1e6, 1)}
+            for c in clones:
+                c.close()
         if args.brief:
-            out = {k: out[k] for k in ("config", "refill_lanes", "Mrays_per_s", "ms_per_frame", "stage_ms")}
+            out = {k: out[k] for k in ("config", "refill_lanes", "Mrays_per_s", "ms_per_frame", "stage_ms", "in_flight") if k in out}
         print(json.dumps(out), flush=True)
         if animated:
             # the same frames through the sequence driver: the host work of frame f+1 (redoAABBs,
