@@ -127,8 +127,8 @@ def main():
             if pending[k] is not None:
                 pending[k].wait()
                 pending[k] = None
-            fbs[h].zero_()
-            st = handles[h].render_device(rd_for(step, flags), fbs[h].data_ptr())
+            # the frame replaces what the buffer held (the reference clears it per frame)
+            st = handles[h].render_device(rd_for(step, flags | abi.FLAG_OVERWRITE), fbs[h].data_ptr())
             handles[h].present_device(fbs[h].data_ptr(), W, H, shown[k].data_ptr(), passes=1, tonemap=abi.TONEMAP_NONE, flip=True)
             if world > 1:
                 src = shown[k] if backend == "nccl" else shown[k].cpu()

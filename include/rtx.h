@@ -213,10 +213,14 @@ enum {
     RTX_FLAG_TRACE_TIMES     = 1u << 12,/* fill only ms_traverse and ms_shadow of the statistics: the
                                            traversal launches; fewer events on the stream than
                                            RTX_FLAG_STAGE_TIMES                               */
-    RTX_FLAG_SERIAL_CHUNKS   = 1u << 13 /* render the tile's chunks one after the other on the
+    RTX_FLAG_SERIAL_CHUNKS   = 1u << 13,/* render the tile's chunks one after the other on the
                                            scene's stream instead of two at a time on the
                                            library's two streams (same image; launches then do
                                            not overlap, so their durations can be measured)   */
+    RTX_FLAG_OVERWRITE       = 1u << 14 /* the call's first pass stores its result in accum
+                                           instead of adding to it (as if the tile had been
+                                           cleared first: clearBuffers, Raytracer.cpp:53-58),
+                                           which saves the caller a fill of the buffer       */
 };
 
 /* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;

@@ -39,6 +39,7 @@ FLAG_GLOBAL_LIGHTING = 1 << 10
 FLAG_REFILL_LANES = 1 << 11
 FLAG_TRACE_TIMES = 1 << 12
 FLAG_SERIAL_CHUNKS = 1 << 13
+FLAG_OVERWRITE = 1 << 14
 
 TONEMAP_NONE, TONEMAP_CBRT = 0, 1
 

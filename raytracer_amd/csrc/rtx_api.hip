@@ -1025,6 +1025,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 Lane& L = lanes[k];
                 if (L.alive || next_t0 >= padded_pixels) continue;
                 L.p.pass = pass;
+                L.p.overwrite = ((rd->flags & RTX_FLAG_OVERWRITE) && pass == rd->first_pass) ? 1u : 0u;
                 L.p.chunk_t0 = (uint32_t)next_t0;
                 L.p.chunk_pixels = (uint32_t)std::min<uint64_t>(pixels_per_chunk, padded_pixels - next_t0);
                 next_t0 += L.p.chunk_pixels;

@@ -70,6 +70,7 @@ struct RenderParams {
     uint32_t gather_samples;    // globalSamples per light (:500); 0 = off
     uint32_t gather_traced;     // 1 when layer+1 <= MAXBOUNCES, i.e. the nested call shoots its ray
     uint32_t atomic_samples;    // 1: several rays of one launch may add to the same sample slot
+    uint32_t overwrite;         // 1: this pass stores into accum instead of adding to it
 };
 
 // ---- traversal core -------------------------------------------------------------------------
@@ -1402,9 +1403,15 @@ k_resolve(RenderParams p, const double* __restrict__ sample, float* accum)
     }
     d3 px = acum / (double)nn;
     size_t at = 3 * ((size_t)(x - p.d.tile_x0) + (size_t)(y - p.d.tile_y0) * p.d.tile_w);
-    accum[at + 0] += (float)px.x;
-    accum[at + 1] += (float)px.y;
-    accum[at + 2] += (float)px.z;
+    if (p.overwrite) {      // 0.0f + float(px): what adding to a cleared buffer gives
+        accum[at + 0] = 0.0f + (float)px.x;
+        accum[at + 1] = 0.0f + (float)px.y;
+        accum[at + 2] = 0.0f + (float)px.z;
+    } else {
+        accum[at + 0] += (float)px.x;
+        accum[at + 1] += (float)px.y;
+        accum[at + 2] += (float)px.z;
+    }
 }
 
 // Ray totals of one level (one thread), so that the host need not read the per-level counters:

@@ -225,6 +225,19 @@ def test_two_chunks_at_a_time_equal_one_after_the_other(gpu, monkeypatch, kind):
     assert np.isfinite(out[0][0]).all() and out[0][0].max() > 0
 
 
+def test_overwrite_flag_equals_cleared_buffer(gpu):
+    """RTX_FLAG_OVERWRITE: the first pass stores, later passes add; a buffer full of other
+    values gives the image a cleared buffer gives."""
+    scene, cam = scenes.whitted_scene()
+    desc = scene.frame(0.0)
+    kw = dict(integrator=abi.INTEGRATOR_PATH, camera=cam, n=2, max_depth=3, passes=3, seed=2, clear=(0.0, 0.0, 0.0))
+    with gpu.DeviceScene(desc) as ds:
+        want, _ = ds.render(scenes.render_desc(90, 60, **kw))
+        junk = np.full((60, 90, 3), -7.5, np.float32)
+        got, _ = ds.render(scenes.render_desc(90, 60, flags=abi.FLAG_OVERWRITE, **kw), accum=junk)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+
+
 def test_linear_scan_equals_kd_image(gpu):
     scene, cam = scenes.lens_scene()
     desc = scene.frame(0.0)
