@@ -188,6 +188,7 @@ struct rtx_scene {
     int device = 0;
     uint32_t kd_depth = 0;
     uint32_t bvh_depth = 0;
+    const float* srgb_thresholds = nullptr;     // device copy of srgb_thresholds(), for k_present
     bool may_refract = false;       // some material can have transparency != 0 (rayTrace spawns a child then)
     std::vector<uint8_t> light_multisample;     // Light::multisample per light, kept on the host
     int compute_units = 0;
@@ -196,6 +197,35 @@ struct rtx_scene {
 };
 
 namespace {
+
+// Where the 8-bit sRGB value of a framebuffer write steps up (GL_FRAMEBUFFER_SRGB, Raytracer.cpp:422):
+// table[b] = the smallest float in [0, 1] whose conversion clamp -> transfer function ->
+// round gives b or more.  Positive floats order like their bit patterns, so each threshold is
+// found by bisection on the bits.
+const float* srgb_thresholds()
+{
+    static float table[256];
+    static const bool ready = [] {
+        auto convert = [](float c) -> int {
+            float e = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+            return (int)(e * 255.0f + 0.5f);
+        };
+        auto as_float = [](uint32_t bits) { float f; std::memcpy(&f, &bits, 4); return f; };
+        const uint32_t one = 0x3f800000u;
+        table[0] = -std::numeric_limits<float>::infinity();
+        for (int b = 1; b < 256; ++b) {
+            uint32_t lo = 0u, hi = one;         // convert(lo) < b <= convert(hi)
+            while (hi - lo > 1u) {
+                uint32_t mid = lo + (hi - lo) / 2u;
+                if (convert(as_float(mid)) >= b) hi = mid; else lo = mid;
+            }
+            table[b] = as_float(hi);
+        }
+        return true;
+    }();
+    (void)ready;
+    return table;
+}
 
 int ensure_workspace(Workspace& w, size_t cap, size_t shadow_cap, size_t gather_cap, bool with_cand)
 {
@@ -555,6 +585,7 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     up(branch_cbox.data(), branch_cbox.size(), &d.branch_cbox);
     up(leaf_cbox.data(), leaf_cbox.size(), &d.leaf_cbox);
     up(bvh.nodes.data(), bvh.nodes.size(), &d.bvh_nodes);
+    up(srgb_thresholds(), 256, &sc->srgb_thresholds);
     up(bvh_prims.data(), bvh_prims.size(), &d.bvh_prims);
     up(prim_leaf_first.data(), prim_leaf_first.size(), &d.prim_leaf_first);
     up(prim_leaf_ids.data(), prim_leaf_ids.size(), &d.prim_leaf_ids);
@@ -604,6 +635,7 @@ int rtx_scene_clone(const rtx_scene* sc, rtx_scene** out)
     c->kd_depth = sc->kd_depth;
     c->bvh_depth = sc->bvh_depth;
     c->may_refract = sc->may_refract;
+    c->srgb_thresholds = sc->srgb_thresholds;
     c->light_multisample = sc->light_multisample;
     c->compute_units = sc->compute_units;
     c->refill_range = sc->refill_range;
@@ -1131,9 +1163,9 @@ int rtx_present_device(rtx_scene* sc, const float* accum, uint32_t width, uint32
     if (!sc || !accum || !rgb8) return fail(RTX_ERR_INVALID, "null argument");
     if (width == 0 || height == 0 || (uint64_t)width * height * 3 > 0xffffffffull) return fail(RTX_ERR_INVALID, "bad frame size");
     if (passes == 0 || tonemap > RTX_TONEMAP_CBRT) return fail(RTX_ERR_INVALID, "bad passes / tonemap");
-    size_t total = (size_t)width * height * 3;
-    hipLaunchKernelGGL(k_present, grid_for(total), dim3(kBlock), 0, sc->stream, accum, width, height, (float)passes, tonemap,
-                       flip ? 1u : 0u, rgb8);
+    if (height > 65535u) return fail(RTX_ERR_LIMIT, "more than 65535 rows");
+    hipLaunchKernelGGL(k_present, dim3(grid_for((size_t)width * 3).x, height), dim3(kBlock), 0, sc->stream, accum, width, height,
+                       (float)passes, tonemap, flip ? 1u : 0u, sc->srgb_thresholds, rgb8);
     HIP_TRY(hipGetLastError());
     if (!sc->async) HIP_TRY(hipStreamSynchronize(sc->stream));
     return RTX_OK;

@@ -1427,27 +1427,35 @@ __global__ void k_level_totals(const uint32_t* next_len, const uint32_t* hits, u
 }
 
 // ---- present (Raytracer.cpp:720-725, :422, :90-105) ------------------------------------------------
-// linear float -> 8-bit sRGB as an sRGB framebuffer stores it: clamp, transfer function, round
-RTX_DEV uint8_t srgb8(float c)
-{
-    if (!(c > 0.0f)) c = 0.0f;              // also NaN -> 0, as framebuffer conversion does
-    if (c > 1.0f) c = 1.0f;
-    float e = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
-    return (uint8_t)(int)(e * 255.0f + 0.5f);
-}
-
+// linear float -> 8-bit sRGB as an sRGB framebuffer stores it: clamp, transfer function, round.
+// The conversion is monotone, so it is a search in the 255 thresholds at which the byte steps
+// up (srgb_thresholds() on the host evaluates the formula with the C library's powf, the one
+// a CPU restatement uses): thresholds[b] is the smallest float that converts to b or more,
+// thresholds[0] is unused.  NaN and values <= 0 give 0, values >= 1 give 255.
 __global__ void __launch_bounds__(kBlock)
 k_present(const float* __restrict__ accum, uint32_t width, uint32_t height, float passes, uint32_t tonemap, uint32_t flip,
-          uint8_t* __restrict__ rgb8)
+          const float* __restrict__ thresholds, uint8_t* __restrict__ rgb8)
 {
-    uint32_t k = blockIdx.x * kBlock + threadIdx.x;          // one thread per channel value
-    uint32_t total = width * height * 3u;
-    if (k >= total) return;
-    float v = accum[k] / passes;
+    __shared__ float t[256];
+    t[threadIdx.x] = thresholds[threadIdx.x];           // kBlock is 256
+    __syncthreads();
+    const uint32_t row_values = width * 3u;
+    const uint32_t in_row = blockIdx.x * kBlock + threadIdx.x;     // one thread per channel value
+    const uint32_t row = blockIdx.y;
+    if (in_row >= row_values) return;
+    float v = accum[(size_t)row * row_values + in_row];
+    if (passes != 1.0f) v = v / passes;
     if (tonemap == RTX_TONEMAP_CBRT) v = cbrtf(v);
-    uint32_t row = k / (width * 3u), in_row = k - row * width * 3u;
-    uint32_t out_row = flip ? height - 1u - row : row;
-    rgb8[out_row * width * 3u + in_row] = srgb8(v);
+    uint32_t lo = 0u, hi = 255u;
+#pragma unroll
+    for (int step = 0; step < 8; ++step) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        const bool up = v >= t[mid];
+        lo = up ? mid : lo;
+        hi = up ? hi : mid - 1u;
+    }
+    const uint32_t out_row = flip ? height - 1u - row : row;
+    rgb8[(size_t)out_row * row_values + in_row] = (uint8_t)lo;
 }
 
 }  // namespace rtx
