@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--serial-chunks", action="store_true",
                     help="render a frame's two half-frame chunks one after the other instead of on two streams: "
                          "launches then run alone, which is how the per-launch figures of the roofline are best read")
+    ap.add_argument("--store-camera-rays", action="store_true",
+                    help="write the camera rays with a generate kernel and read them back (RTX_FLAG_STORE_CAMERA_RAYS) "
+                         "instead of computing them in the kernels of level 0; same image, for comparison")
     ap.add_argument("--no-serial-leg", action="store_true",
                     help="skip the untimed repeat of the frames with chunks one after the other (roofline.serial)")
     ap.add_argument("--walk", choices=["bvh", "kd-culled", "reference"], default="bvh",
@@ -100,6 +103,8 @@ def main():
     F = max(1, args.in_flight)
     if args.serial_chunks or F > 1:     # frames in flight overlap each other; their chunks need not
         kflags |= abi.FLAG_SERIAL_CHUNKS
+    if args.store_camera_rays:
+        kflags |= abi.FLAG_STORE_CAMERA_RAYS
     stream = torch.cuda.current_stream().cuda_stream
     ds = device.DeviceScene(desc, stream=stream)
     # handle k renders the frames with step % F == k on stream k

@@ -217,10 +217,17 @@ enum {
                                            scene's stream instead of two at a time on the
                                            library's two streams (same image; launches then do
                                            not overlap, so their durations can be measured)   */
-    RTX_FLAG_OVERWRITE       = 1u << 14 /* the call's first pass stores its result in accum
+    RTX_FLAG_OVERWRITE       = 1u << 14,/* the call's first pass stores its result in accum
                                            instead of adding to it (as if the tile had been
                                            cleared first: clearBuffers, Raytracer.cpp:53-58),
                                            which saves the caller a fill of the buffer       */
+    RTX_FLAG_STORE_CAMERA_RAYS = 1u << 15 /* a generate kernel writes the camera rays into the
+                                           first ray queue and the kernels of level 0 read them
+                                           back, as every later level does.  Without it those
+                                           kernels compute the camera ray from the sample slot
+                                           (same arithmetic, same image; 84 bytes per ray less
+                                           to write and to read three times).  Implied by
+                                           RTX_FLAG_REFILL_LANES                              */
 };
 
 /* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;

@@ -737,8 +737,11 @@ static void hand_out_stats(rtx_scene* sc, rtx_stats* out)
 
 static int launch_trace(rtx_scene* sc, Workspace& ws, hipStream_t stream, const double* ox, const double* oy, const double* oz,
                         const double* dx, const double* dy, const double* dz, const double* limit, uint32_t n,
-                        const uint32_t* n_device, uint32_t seg, uint32_t flags, int32_t* hit_prim, double* hit_depth, bool count)
+                        const uint32_t* n_device, uint32_t seg, uint32_t flags, int32_t* hit_prim, double* hit_depth, bool count,
+                        const CameraQueue* camera = nullptr)
 {
+    CameraQueue cam;
+    if (camera) cam = *camera; else std::memset(&cam, 0, sizeof cam);
     uint32_t linear = (flags & RTX_FLAG_LINEAR_SCAN) ? 1u : 0u;
     int mode;
     if (flags & (RTX_FLAG_REFERENCE_ORDER | RTX_FLAG_LINEAR_SCAN)) mode = 0;
@@ -752,6 +755,7 @@ static int launch_trace(rtx_scene* sc, Workspace& ws, hipStream_t stream, const 
     if (threads > 0xffffffffull) return fail(RTX_ERR_LIMIT, "more than 2^32 light rays in one launch: lower RTX_MAX_PATHS");
     dim3 grid = trace_grid_for(threads), block(kTraceBlock);
     if (mode >= 3 && (flags & RTX_FLAG_REFILL_LANES) && n <= ws.cand_capacity) {
+        if (cam.on) return fail(RTX_ERR_INVALID, "the refilled walk reads stored camera rays");
         // lanes refilled from the wave's own range of the queue; ranges shrink for small launches
         // so that every resident wave slot gets several
         const int anyhit = limit ? 1 : 0;
@@ -774,7 +778,7 @@ static int launch_trace(rtx_scene* sc, Workspace& ws, hipStream_t stream, const 
     }
 #define RTX_LAUNCH_TRACE(COUNT, MODE)                                                                                  \
     hipLaunchKernelGGL((k_trace_pool<COUNT, MODE>), grid, block, 0, stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
-                       n_device, seg, linear, hit_prim, hit_depth, g)
+                       n_device, seg, linear, hit_prim, hit_depth, g, cam)
 #define RTX_LAUNCH_MODES(COUNT)                                                                   \
     switch (mode) {                                                                               \
     case 0: RTX_LAUNCH_TRACE(COUNT, 0); break;                                                    \
@@ -903,6 +907,10 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     // launched for an upper bound of their length without waiting (surplus workgroups leave at
     // once), with a readback every fourth level.
     const bool sync_every_level = fan_out > 1 || (rd->flags & RTX_FLAG_SORT_MATERIAL);
+    // Level 0 needs no stored queue: its kernels compute the camera ray of their sample slot, and
+    // the level's traversal launch, the first of a chunk, clears the chunk's state.  The refilled
+    // walk's kernels read rays from memory only.
+    const bool camera_queue = !(rd->flags & (RTX_FLAG_STORE_CAMERA_RAYS | RTX_FLAG_REFILL_LANES));
     const uint32_t kLongLevel = 4u << 20;
 
     struct Lane {
@@ -954,8 +962,12 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         L.trace_timer_p->begin();
         // the shading kernels recompute the hit from its id: the depth is only kept for
         // the refilled walk's verification pass
+        lp.layer = level;
+        lp.camera_queue = (camera_queue && level == 0) ? 1u : 0u;
+        CameraQueue cq;
+        cq.p = lp; cq.sample = w.sample; cq.counts = w.counts; cq.on = lp.camera_queue;
         int r = launch_trace(sc, w, st, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, bound, n_dev, 0, rd->flags, q.hit_prim,
-                             (rd->flags & RTX_FLAG_REFILL_LANES) ? q.hit_depth : nullptr, count_work);
+                             (rd->flags & RTX_FLAG_REFILL_LANES) ? q.hit_depth : nullptr, count_work, &cq);
         if (r != RTX_OK) return r;
         L.trace_timer_p->end(&local.ms_traverse);
         local.traverse_launches++;
@@ -1062,10 +1074,12 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
                 L.p.chunk_pixels = (uint32_t)std::min<uint64_t>(pixels_per_chunk, padded_pixels - next_t0);
                 next_t0 += L.p.chunk_pixels;
                 const size_t slots = (size_t)L.p.chunk_pixels * nn;
-                L.timer_p->begin();
-                hipLaunchKernelGGL(k_generate, grid_for(slots), dim3(kBlock), 0, L.st, L.p, L.w->q[0], L.w->sample, L.w->counts);
-                HIP_TRY(hipGetLastError());
-                L.timer_p->end(&local.ms_generate);
+                if (!camera_queue) {
+                    L.timer_p->begin();
+                    hipLaunchKernelGGL(k_generate, grid_for(slots), dim3(kBlock), 0, L.st, L.p, L.w->q[0], L.w->sample, L.w->counts);
+                    HIP_TRY(hipGetLastError());
+                    L.timer_p->end(&local.ms_generate);
+                }
                 local.rays_primary += slots;
                 local.max_queue = std::max<uint32_t>(local.max_queue, (uint32_t)slots);
                 L.bound = (uint32_t)slots;      // one camera ray per sample slot

@@ -71,6 +71,17 @@ struct RenderParams {
     uint32_t gather_traced;     // 1 when layer+1 <= MAXBOUNCES, i.e. the nested call shoots its ray
     uint32_t atomic_samples;    // 1: several rays of one launch may add to the same sample slot
     uint32_t overwrite;         // 1: this pass stores into accum instead of adding to it
+    uint32_t camera_queue;      // 1: the queue being shaded is level 0 and is not stored: ray i is the camera
+                                //   ray of sample slot i, its weight 1, its random stream at (0, 0)
+};
+
+// What the traversal launch of such a level needs to make its own rays and to clear the
+// chunk's state (it is the chunk's first launch).
+struct CameraQueue {
+    RenderParams p;             // meaningful when `on`
+    double* sample;             // the chunk's accumulator, 3 doubles per sample slot
+    uint32_t* counts;           // the ring of queue lengths (8 words)
+    uint32_t on;
 };
 
 // ---- traversal core -------------------------------------------------------------------------
@@ -645,6 +656,63 @@ RTX_DEV void add_static_efficiency(Counters g, const Work<true>& w)
 }
 RTX_DEV void add_static_efficiency(Counters, const Work<false>&) {}
 
+// ---- pixel <-> slot mapping ------------------------------------------------------------------
+// Pixel index t in [0, tile_w*tile_h) walks the tile in bands of 8 rows and, inside a band,
+// in blocks of 8 columns (the last band / block may be narrower), so that the 64 lanes of a
+// wave are neighbouring pixels.  Every t is a pixel: nothing needs compacting away.
+RTX_DEV void pixel_of(const RenderParams& p, uint32_t t, uint32_t& x, uint32_t& y)
+{
+    const uint32_t W = p.d.tile_w, H = p.d.tile_h;
+    uint32_t band = t / (8u * W);
+    uint32_t r = t - band * 8u * W;
+    uint32_t hb = min(8u, H - 8u * band);
+    uint32_t bx = r / (8u * hb);
+    uint32_t r2 = r - bx * 8u * hb;
+    uint32_t wb = min(8u, W - 8u * bx);
+    uint32_t ly = r2 / wb, lx = r2 - ly * wb;
+    x = p.d.tile_x0 + bx * 8u + lx;
+    y = p.d.tile_y0 + band * 8u + ly;
+}
+
+// The camera ray of sample slot `slot` of the chunk (Raytracer.cpp:676-700).
+RTX_DEV Ray camera_ray(const RenderParams& p, uint32_t slot)
+{
+    uint32_t nn = p.n * p.n;
+    uint32_t t = p.chunk_t0 + slot / nn, sub = slot % nn;
+    uint32_t x, y;
+    pixel_of(p, t, x, y);
+    uint32_t sx = sub / p.n + 1, sy = sub % p.n + 1;
+    const rtx_camera& c = p.d.camera;
+    double nx = ((double)x / (double)p.d.width) - 0.5;
+    double ny = ((double)y / (double)p.d.height) - 0.5;
+    d3 eye = ld3(c.eye);
+    d3 on_screen = (((ld3(c.right) * nx) + (ld3(c.up) * ny)) + eye) + (ld3(c.forward) * c.focal);
+    double cx = 1.0 / ((double)p.d.width - 1.0), cy = 1.0 / ((double)p.d.height - 1.0);
+    double offx = (double)sx * (cx / (double)(p.n + 1));
+    double offy = (double)sy * (cy / (double)(p.n + 1));
+    d3 v = normalize3((on_screen + mk(offx, offy, 0.0)) - eye);
+    return make_ray(eye, v);
+}
+
+// The queue of level 0 holds nothing that cannot be recomputed: ray i is sample slot i, its
+// weight is 1, its random stream starts at (branch 0, counter 0) and origin and direction are
+// the camera's.  With p.camera_queue set the kernels of level 0 therefore compute those
+// instead of reading them, and nothing writes them: 84 bytes per camera ray that are neither
+// stored by a generate kernel nor fetched by the traversal and by each shading kernel.
+RTX_DEV Ray queue_ray(const RenderParams& p, const RayQueue& q, uint32_t i)
+{
+    if (p.camera_queue) return camera_ray(p, i);
+    Ray r;
+    r.o = mk(q.ox[i], q.oy[i], q.oz[i]);
+    r.d = mk(q.dx[i], q.dy[i], q.dz[i]);
+    return r;
+}
+RTX_DEV uint32_t queue_slot(const RenderParams& p, const RayQueue& q, uint32_t i) { return p.camera_queue ? i : q.slot[i]; }
+RTX_DEV d3 queue_weight(const RenderParams& p, const RayQueue& q, uint32_t i)
+{
+    return p.camera_queue ? mk(1.0, 1.0, 1.0) : mk(q.wx[i], q.wy[i], q.wz[i]);
+}
+
 // Which ray a thread (or a refilled lane) works on.  Flat queues (seg == 0): ray i of the first
 // min(n, *n_device) entries, origin and direction at i.  Light-ray queues (seg != 0, n = samples
 // * seg): the level's *n_device hits times n / seg samples.  They are enumerated in tiles of
@@ -721,7 +789,7 @@ __global__ void __launch_bounds__(kTraceBlock)
 k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
              const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
              const double* __restrict__ limit, uint32_t n, const uint32_t* __restrict__ n_device, uint32_t seg,
-             uint32_t linear, int32_t* hit_prim, double* hit_depth, Counters g)
+             uint32_t linear, int32_t* hit_prim, double* hit_depth, Counters g, CameraQueue cam)
 {
     __shared__ int32_t stack[kStack * kTraceBlock];
     const uint32_t ray = blockIdx.x * kTraceBlock + threadIdx.x;
@@ -730,7 +798,19 @@ k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__
     if (ray >= ray_total(n, n_device, seg)) return;
     uint32_t i, at;
     if (!ray_place(ray, n, n_device, seg, i, at)) return;
-    d3 o = mk(ox[at], oy[at], oz[at]), d = mk(dx[i], dy[i], dz[i]);
+    d3 o, d;
+    if (cam.on) {
+        // level 0 of a chunk: ray i is the camera ray of sample slot i.  This launch is also the
+        // first of the chunk, so it clears the chunk's state: the slot's accumulator and the
+        // ring of queue lengths.
+        if (ray < 8u) cam.counts[ray] = 0u;
+        double* acc = cam.sample + 3 * (size_t)i;
+        acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0;
+        const Ray r = camera_ray(cam.p, i);
+        o = r.o; d = r.d;
+    } else {
+        o = mk(ox[at], oy[at], oz[at]); d = mk(dx[i], dy[i], dz[i]);
+    }
     Work<COUNT> w;
     int32_t bp = -1; double bd = kInf;
     bool settled = false;
@@ -959,24 +1039,6 @@ k_verify(DScene s, const double* __restrict__ ox, const double* __restrict__ oy,
     add_counters(g, w);
 }
 
-// ---- pixel <-> slot mapping ------------------------------------------------------------------
-// Pixel index t in [0, tile_w*tile_h) walks the tile in bands of 8 rows and, inside a band,
-// in blocks of 8 columns (the last band / block may be narrower), so that the 64 lanes of a
-// wave are neighbouring pixels.  Every t is a pixel: nothing needs compacting away.
-RTX_DEV void pixel_of(const RenderParams& p, uint32_t t, uint32_t& x, uint32_t& y)
-{
-    const uint32_t W = p.d.tile_w, H = p.d.tile_h;
-    uint32_t band = t / (8u * W);
-    uint32_t r = t - band * 8u * W;
-    uint32_t hb = min(8u, H - 8u * band);
-    uint32_t bx = r / (8u * hb);
-    uint32_t r2 = r - bx * 8u * hb;
-    uint32_t wb = min(8u, W - 8u * bx);
-    uint32_t ly = r2 / wb, lx = r2 - ly * wb;
-    x = p.d.tile_x0 + bx * 8u + lx;
-    y = p.d.tile_y0 + band * 8u + ly;
-}
-
 // Block-wide reservation of queue space: one atomic per workgroup.  Every thread of the
 // workgroup must call it.  `lds` is kBlock/64 + 2 words of scratch.
 RTX_DEV uint32_t block_reserve(bool pred, uint32_t* counter, uint32_t per_item, uint32_t* lds, uint32_t* block_total = nullptr,
@@ -1019,22 +1081,9 @@ k_generate(RenderParams p, RayQueue q, double* sample, uint32_t* counts)
     uint32_t nn = p.n * p.n;
     uint32_t total = p.chunk_pixels * nn;
     if (slot >= total || slot >= p.queue_cap) return;
-    uint32_t t = p.chunk_t0 + slot / nn, sub = slot % nn;
-    uint32_t x, y;
-    pixel_of(p, t, x, y);
-    uint32_t sx = sub / p.n + 1, sy = sub % p.n + 1;
-    const rtx_camera& c = p.d.camera;
-    double nx = ((double)x / (double)p.d.width) - 0.5;
-    double ny = ((double)y / (double)p.d.height) - 0.5;
-    d3 eye = ld3(c.eye);
-    d3 on_screen = (((ld3(c.right) * nx) + (ld3(c.up) * ny)) + eye) + (ld3(c.forward) * c.focal);
-    double cx = 1.0 / ((double)p.d.width - 1.0), cy = 1.0 / ((double)p.d.height - 1.0);
-    double offx = (double)sx * (cx / (double)(p.n + 1));
-    double offy = (double)sy * (cy / (double)(p.n + 1));
-    d3 v = normalize3((on_screen + mk(offx, offy, 0.0)) - eye);
     sample[3 * (size_t)slot + 0] = 0.0; sample[3 * (size_t)slot + 1] = 0.0; sample[3 * (size_t)slot + 2] = 0.0;
     // ray i of the first queue is sample slot i
-    push_ray(q, slot, make_ray(eye, v), mk(1.0, 1.0, 1.0), slot, 0u, 0u);
+    push_ray(q, slot, camera_ray(p, slot), mk(1.0, 1.0, 1.0), slot, 0u, 0u);
 }
 
 RTX_DEV void sample_add(const RenderParams& p, double* sample, uint32_t slot, d3 v)
@@ -1062,7 +1111,9 @@ RTX_DEV Rng ray_rng(const RenderParams& p, const RayQueue& q, uint32_t i, uint32
     pixel_of(p, t, x, y);
     Rng r;
     r.seed = p.d.seed; r.frame = p.d.frame; r.pixel = x + y * p.d.width;
-    r.sample = p.pass * nn + sub; r.branch = q.branch[i]; r.counter = q.counter[i];
+    r.sample = p.pass * nn + sub;
+    r.branch = p.camera_queue ? 0u : q.branch[i];
+    r.counter = p.camera_queue ? 0u : q.counter[i];
     return r;
 }
 
@@ -1140,14 +1191,15 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
     Ray child; d3 cw = mk(0, 0, 0); uint32_t slot = 0, cbranch = 0, ccounter = 0;
     const uint32_t layer = p.layer;
     if (live) {
-        slot = q.slot[i];
-        d3 w = mk(q.wx[i], q.wy[i], q.wz[i]);
+        slot = queue_slot(p, q, i);
+        d3 w = queue_weight(p, q, i);
         d3 clear = ld3(p.d.clear_color);
         int32_t prim = q.hit_prim[i];
         if (prim < 0) {
             sample_add(p, sample, slot, w * (clear * 0.1));
         } else {
-            d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
+            const Ray qr = queue_ray(p, q, i);
+            d3 o = qr.o, d = qr.d;
             d3 inv_dir = -d;
             Hit h;
             prim_full(s, (uint32_t)prim, o, d, h);
@@ -1233,7 +1285,7 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
     if (i < n) {
         int32_t prim = q.hit_prim[i];
         if (prim < 0) {
-            sample_add(p, sample, q.slot[i], mk(q.wx[i], q.wy[i], q.wz[i]) * ld3(p.d.clear_color));
+            sample_add(p, sample, queue_slot(p, q, i), queue_weight(p, q, i) * ld3(p.d.clear_color));
         } else {
             hit = true;
         }
@@ -1246,10 +1298,11 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
     const uint32_t h_index = block_reserve(emit, hit_count, 1, reserve_lds);     // < seg: at most one per ray
     if (i < n) hit_index[i] = h_index;
     if (emit) {
-        d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
+        const Ray qr = queue_ray(p, q, i);
+        d3 o = qr.o, d = qr.d;
         Hit h;
         prim_full(s, (uint32_t)q.hit_prim[i], o, d, h);
-        uint32_t slot = q.slot[i];
+        uint32_t slot = queue_slot(p, q, i);
         Rng rng = ray_rng(p, q, i, slot);
         d3 from = h.position + (h.normal * p.d.bias);
         // Light::getRay starts every light ray of this hit at `from` (Ray.cpp:3-8 keeps the origin)
@@ -1281,6 +1334,8 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
             }
         }
         q.counter[i] = rng.counter;       // the refraction child continues this stream
+    } else if (hit && p.camera_queue) {
+        q.counter[i] = 0u;                // nothing has written this ray's counter yet
     }
 }
 
@@ -1297,10 +1352,11 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
     double ni = 1.0; uint32_t slot = 0, branch = 0, counter = 0;
     const uint32_t layer = p.layer;
     if (i < n && q.hit_prim[i] >= 0) {
-        slot = q.slot[i]; branch = q.branch[i]; counter = q.counter[i];
-        d3 w = mk(q.wx[i], q.wy[i], q.wz[i]);
+        slot = queue_slot(p, q, i); branch = p.camera_queue ? 0u : q.branch[i]; counter = q.counter[i];
+        d3 w = queue_weight(p, q, i);
         d3 clear = ld3(p.d.clear_color);
-        d3 o = mk(q.ox[i], q.oy[i], q.oz[i]), d = mk(q.dx[i], q.dy[i], q.dz[i]);
+        const Ray qr = queue_ray(p, q, i);
+        d3 o = qr.o, d = qr.d;
         d3 inv_dir = -d;
         Hit h;
         prim_full(s, (uint32_t)q.hit_prim[i], o, d, h);

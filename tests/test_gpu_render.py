@@ -225,6 +225,54 @@ def test_two_chunks_at_a_time_equal_one_after_the_other(gpu, monkeypatch, kind):
     assert np.isfinite(out[0][0]).all() and out[0][0].max() > 0
 
 
+@pytest.mark.parametrize("kind", ["path", "whitted_soft", "whitted_refract", "whitted_reflect", "gather", "sorted", "walks"])
+def test_computed_camera_rays_equal_stored_ones(gpu, monkeypatch, kind):
+    """Level 0 is rendered without a stored queue by default (its kernels compute the camera ray
+    of their sample slot); RTX_FLAG_STORE_CAMERA_RAYS writes the rays with a generate kernel and
+    reads them back.  Images, ray counts and traversal work are equal bit for bit, over several
+    chunks and passes, whichever walk traces the rays."""
+    flags = 0
+    if kind in ("path", "sorted"):
+        scene, cam = scenes.lens_scene()
+        kw = dict(integrator=abi.INTEGRATOR_PATH, n=2, max_depth=8, bias=1e-4, passes=2)
+        flags = abi.FLAG_SORT_MATERIAL if kind == "sorted" else 0
+    elif kind == "whitted_soft":
+        scene, cam = scenes.mesh_scene(slices=60, stacks=30, ggx=True, square_light=True)
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=2, max_depth=3, bias=1e-2, light_n=2)
+    elif kind == "whitted_refract":       # the refraction child continues the camera ray's random stream
+        scene, cam = scenes.whitted_scene()
+        scene.square_light((0.0, 9.0, 2.0), (0.0, -1.0, 0.0), 2.0, 2.0)
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=2, max_depth=5, light_n=2)
+    elif kind == "whitted_reflect":
+        scene, cam = scenes.whitted_scene()
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=1, max_depth=3)
+        flags = abi.FLAG_WHITTED_REFLECT
+    elif kind == "gather":
+        scene, cam = scenes.whitted_scene()
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=1, max_depth=2, global_samples=6)
+        flags = abi.FLAG_GLOBAL_LIGHTING
+    else:
+        scene, cam = scenes.mesh_scene(slices=60, stacks=30)
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=1, max_depth=2)
+    desc = scene.frame(0.2)
+    monkeypatch.setenv("RTX_TWO_LANE_MIN", "128")
+    monkeypatch.setenv("RTX_MAX_PATHS", "8192")
+    walks = (0, abi.FLAG_KD_CULLED, abi.FLAG_REFERENCE_ORDER, abi.FLAG_LINEAR_SCAN) if kind == "walks" else (0,)
+    with gpu.DeviceScene(desc) as ds:
+        for walk in walks:
+            f = flags | walk | abi.FLAG_COUNTERS
+            a, sa = ds.render(scenes.render_desc(150, 90, camera=cam, flags=f, **kw))
+            b, sb = ds.render(scenes.render_desc(150, 90, camera=cam, flags=f | abi.FLAG_STORE_CAMERA_RAYS, **kw))
+            _same_ray_counts(sa, sb)
+            for k in ("content_tests", "triangle_tests", "sphere_tests", "aabb_tests", "hits_accepted", "fallback_rays"):
+                assert getattr(sa, k) == getattr(sb, k), k
+            if kind == "whitted_reflect":       # several rays add into one sample slot, in any order
+                assert rel_err(a, b).max() < 1e-6
+            else:
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            assert np.isfinite(a).all() and a.max() > 0
+
+
 def test_overwrite_flag_equals_cleared_buffer(gpu):
     """RTX_FLAG_OVERWRITE: the first pass stores, later passes add; a buffer full of other
     values gives the image a cleared buffer gives."""

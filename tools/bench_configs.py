@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--sort-material", action="store_true", help="shade pathTrace levels in material order")
     ap.add_argument("--refill-lanes", action="store_true", help="BVH walk with finished lanes refilled from the queue")
+    ap.add_argument("--store-camera-rays", action="store_true", help="camera rays written by a generate kernel and read back")
     ap.add_argument("--serial", action="store_true", help="one chunk at a time on the caller's stream (no two-lane overlap)")
     ap.add_argument("--no-stage-times", action="store_true", help="no per-stage events (their gaps cost time on short frames)")
     ap.add_argument("--in-flight", type=int, default=1,
@@ -103,6 +104,7 @@ def main():
             rd.flags |= (0 if args.no_stage_times else abi.FLAG_STAGE_TIMES) | (abi.FLAG_SORT_MATERIAL if args.sort_material else 0)
             rd.flags |= abi.FLAG_SERIAL_CHUNKS if args.serial else 0
             rd.flags |= abi.FLAG_REFILL_LANES if args.refill_lanes else 0
+            rd.flags |= abi.FLAG_STORE_CAMERA_RAYS if args.store_camera_rays else 0
             st = ds.render_device(rd, fb.data_ptr())
             for k in rays:
                 rays[k] += getattr(st, k)
