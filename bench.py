@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--store-camera-rays", action="store_true",
                     help="write the camera rays with a generate kernel and read them back (RTX_FLAG_STORE_CAMERA_RAYS) "
                          "instead of computing them in the kernels of level 0; same image, for comparison")
+    ap.add_argument("--accumulate-samples", action="store_true",
+                    help="clear the sample slots, add every term and resolve (RTX_FLAG_ACCUMULATE_SAMPLES) instead of "
+                         "storing finished samples; same image, for comparison")
     ap.add_argument("--no-serial-leg", action="store_true",
                     help="skip the untimed repeat of the frames with chunks one after the other (roofline.serial)")
     ap.add_argument("--walk", choices=["bvh", "kd-culled", "reference"], default="bvh",
@@ -105,6 +108,8 @@ def main():
         kflags |= abi.FLAG_SERIAL_CHUNKS
     if args.store_camera_rays:
         kflags |= abi.FLAG_STORE_CAMERA_RAYS
+    if args.accumulate_samples:
+        kflags |= abi.FLAG_ACCUMULATE_SAMPLES
     stream = torch.cuda.current_stream().cuda_stream
     ds = device.DeviceScene(desc, stream=stream)
     # handle k renders the frames with step % F == k on stream k

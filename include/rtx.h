@@ -221,13 +221,20 @@ enum {
                                            instead of adding to it (as if the tile had been
                                            cleared first: clearBuffers, Raytracer.cpp:53-58),
                                            which saves the caller a fill of the buffer       */
-    RTX_FLAG_STORE_CAMERA_RAYS = 1u << 15 /* a generate kernel writes the camera rays into the
+    RTX_FLAG_STORE_CAMERA_RAYS = 1u << 15,/* a generate kernel writes the camera rays into the
                                            first ray queue and the kernels of level 0 read them
                                            back, as every later level does.  Without it those
                                            kernels compute the camera ray from the sample slot
                                            (same arithmetic, same image; 84 bytes per ray less
                                            to write and to read three times).  Implied by
                                            RTX_FLAG_REFILL_LANES                              */
+    RTX_FLAG_ACCUMULATE_SAMPLES = 1u << 16 /* every term of a sub-sample is added to a cleared
+                                           accumulator slot and a resolve launch sums the slots
+                                           of a pixel.  Without it a slot whose whole value comes
+                                           from one thread (pathTrace: always; rayTrace: when no
+                                           material refracts) is stored once, and with one
+                                           sub-sample per pixel written to the framebuffer at
+                                           once.  Same image                                  */
 };
 
 /* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;

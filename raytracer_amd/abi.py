@@ -41,6 +41,7 @@ FLAG_TRACE_TIMES = 1 << 12
 FLAG_SERIAL_CHUNKS = 1 << 13
 FLAG_OVERWRITE = 1 << 14
 FLAG_STORE_CAMERA_RAYS = 1 << 15
+FLAG_ACCUMULATE_SAMPLES = 1 << 16
 
 TONEMAP_NONE, TONEMAP_CBRT = 0, 1
 

@@ -911,6 +911,12 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     // the level's traversal launch, the first of a chunk, clears the chunk's state.  The refilled
     // walk's kernels read rays from memory only.
     const bool camera_queue = !(rd->flags & (RTX_FLAG_STORE_CAMERA_RAYS | RTX_FLAG_REFILL_LANES));
+    // Sample slots that get their whole value from one thread of one launch are stored instead of
+    // cleared, added to and read back: always so for pathTrace (weight x terminal radiance, added
+    // once per path), for rayTrace when it spawns no children.  With one sub-sample per pixel the
+    // value goes straight into the framebuffer and the resolve launch is left out.
+    const uint32_t direct_store = (rd->flags & RTX_FLAG_ACCUMULATE_SAMPLES) ? 0u
+                                  : (!whitted || (single_level && !p.atomic_samples)) ? (nn == 1 ? 2u : 1u) : 0u;
     const uint32_t kLongLevel = 4u << 20;
 
     struct Lane {
@@ -936,6 +942,8 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         L.timer_p->on = time_all; L.trace_timer_p->on = time_trace;
         L.timer_p->stream = L.trace_timer_p->stream = L.st;
         L.p = p;
+        L.p.direct_store = direct_store;
+        L.p.accum = accum;
         L.p.queue_cap = (uint32_t)std::min<size_t>(L.w->capacity, 0xffffffffu);
         if (n_lanes > 1) HIP_TRY(hipStreamWaitEvent(L.st, sc->fork_event, 0));
     }
@@ -966,6 +974,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         lp.camera_queue = (camera_queue && level == 0) ? 1u : 0u;
         CameraQueue cq;
         cq.p = lp; cq.sample = w.sample; cq.counts = w.counts; cq.on = lp.camera_queue;
+        cq.clear_samples = direct_store ? 0u : 1u;
         int r = launch_trace(sc, w, st, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, bound, n_dev, 0, rd->flags, q.hit_prim,
                              (rd->flags & RTX_FLAG_REFILL_LANES) ? q.hit_depth : nullptr, count_work, &cq);
         if (r != RTX_OK) return r;
@@ -1053,6 +1062,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         return RTX_OK;
     };
     auto finish_chunk = [&](Lane& L) -> int {
+        if (direct_store == 2u) { L.alive = false; return RTX_OK; }      // the shading kernels wrote the pixels
         L.timer_p->begin();
         hipLaunchKernelGGL(k_resolve, grid_for(L.p.chunk_pixels), dim3(kBlock), 0, L.st, L.p, L.w->sample, accum);
         HIP_TRY(hipGetLastError());

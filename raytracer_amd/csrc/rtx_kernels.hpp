@@ -73,6 +73,13 @@ struct RenderParams {
     uint32_t overwrite;         // 1: this pass stores into accum instead of adding to it
     uint32_t camera_queue;      // 1: the queue being shaded is level 0 and is not stored: ray i is the camera
                                 //   ray of sample slot i, its weight 1, its random stream at (0, 0)
+    uint32_t direct_store;      // 0: sample slots are cleared and added to.  1: every slot gets its whole value
+                                //   from one thread of one launch (a pathTrace sample is weight x terminal
+                                //   radiance, added once; a rayTrace call without children is finished by the
+                                //   thread that shades its hit or miss), so slots are stored, neither cleared
+                                //   nor read back.  2: as 1 with one sub-sample per pixel: the value goes
+                                //   straight into the framebuffer and no resolve launch follows
+    float* accum;               // the framebuffer (direct_store == 2)
 };
 
 // What the traversal launch of such a level needs to make its own rays and to clear the
@@ -82,6 +89,7 @@ struct CameraQueue {
     double* sample;             // the chunk's accumulator, 3 doubles per sample slot
     uint32_t* counts;           // the ring of queue lengths (8 words)
     uint32_t on;
+    uint32_t clear_samples;     // 0 when the slots are stored, not added to (RenderParams::direct_store)
 };
 
 // ---- traversal core -------------------------------------------------------------------------
@@ -804,8 +812,10 @@ k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__
         // first of the chunk, so it clears the chunk's state: the slot's accumulator and the
         // ring of queue lengths.
         if (ray < 8u) cam.counts[ray] = 0u;
-        double* acc = cam.sample + 3 * (size_t)i;
-        acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0;
+        if (cam.clear_samples) {
+            double* acc = cam.sample + 3 * (size_t)i;
+            acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0;
+        }
         const Ray r = camera_ray(cam.p, i);
         o = r.o; d = r.d;
     } else {
@@ -1081,7 +1091,7 @@ k_generate(RenderParams p, RayQueue q, double* sample, uint32_t* counts)
     uint32_t nn = p.n * p.n;
     uint32_t total = p.chunk_pixels * nn;
     if (slot >= total || slot >= p.queue_cap) return;
-    sample[3 * (size_t)slot + 0] = 0.0; sample[3 * (size_t)slot + 1] = 0.0; sample[3 * (size_t)slot + 2] = 0.0;
+    if (!p.direct_store) { sample[3 * (size_t)slot + 0] = 0.0; sample[3 * (size_t)slot + 1] = 0.0; sample[3 * (size_t)slot + 2] = 0.0; }
     // ray i of the first queue is sample slot i
     push_ray(q, slot, camera_ray(p, slot), mk(1.0, 1.0, 1.0), slot, 0u, 0u);
 }
@@ -1100,6 +1110,58 @@ RTX_DEV void sample_add(const RenderParams& p, double* sample, uint32_t slot, d3
         unsafeAtomicAdd(at + 2, v.z);
     } else {
         at[0] += v.x; at[1] += v.y; at[2] += v.z;
+    }
+}
+
+// drawBuffer[x + y*frameX] += colorAcum / double(n*n) (Raytracer.cpp:710) for pixel k of the
+// chunk: the quotient is rounded to float and added in FP32 (or stored: 0.0f + it is what
+// adding to a cleared buffer gives).
+RTX_DEV void resolve_pixel(const RenderParams& p, uint32_t k, d3 acum, float* accum)
+{
+    uint32_t x, y;
+    pixel_of(p, p.chunk_t0 + k, x, y);
+    d3 px = acum / (double)(p.n * p.n);
+    size_t at = 3 * ((size_t)(x - p.d.tile_x0) + (size_t)(y - p.d.tile_y0) * p.d.tile_w);
+    if (p.overwrite) {
+        accum[at + 0] = 0.0f + (float)px.x;
+        accum[at + 1] = 0.0f + (float)px.y;
+        accum[at + 2] = 0.0f + (float)px.z;
+    } else {
+        accum[at + 0] += (float)px.x;
+        accum[at + 1] += (float)px.y;
+        accum[at + 2] += (float)px.z;
+    }
+}
+
+// The whole value of a sample slot (p.direct_store != 0): what the cleared slot would hold after
+// its additions, 0.0 + v, is stored -- or, with one sub-sample per pixel, resolved at once
+// (colorAcum = 0 + that value, Raytracer.cpp:690-705).
+RTX_DEV void sample_store(const RenderParams& p, double* sample, uint32_t slot, d3 v)
+{
+    v = mk(0.0 + v.x, 0.0 + v.y, 0.0 + v.z);
+    if (p.direct_store == 2u) {
+        resolve_pixel(p, slot, mk(0.0, 0.0, 0.0) + v, p.accum);
+    } else {
+        double* at = sample + 3 * (size_t)slot;
+        at[0] = v.x; at[1] = v.y; at[2] = v.z;
+    }
+}
+
+// A term of a slot that gets exactly one term (pathTrace): stored or added, as the mode says.
+RTX_DEV void sample_term(const RenderParams& p, double* sample, uint32_t slot, d3 v)
+{
+    if (p.direct_store) sample_store(p, sample, slot, v);
+    else sample_add(p, sample, slot, v);
+}
+
+// A term of a slot whose terms all come from this thread (rayTrace without children): kept in
+// `sum`, which starts at zero and is stored by the caller, or added to the slot at once.
+RTX_DEV void sample_term(const RenderParams& p, double* sample, uint32_t slot, d3 v, d3& sum)
+{
+    if (p.direct_store) {
+        if (!(v.x == 0.0 && v.y == 0.0 && v.z == 0.0)) sum = sum + v;      // as sample_add: zero terms change nothing
+    } else {
+        sample_add(p, sample, slot, v);
     }
 }
 
@@ -1196,7 +1258,7 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
         d3 clear = ld3(p.d.clear_color);
         int32_t prim = q.hit_prim[i];
         if (prim < 0) {
-            sample_add(p, sample, slot, w * (clear * 0.1));
+            sample_term(p, sample, slot, w * (clear * 0.1));
         } else {
             const Ray qr = queue_ray(p, q, i);
             d3 o = qr.o, d = qr.d;
@@ -1205,7 +1267,7 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
             prim_full(s, (uint32_t)prim, o, d, h);
             const rtx_material& m = s.materials[s.prim_material[prim]];
             if (p.d.flags & RTX_FLAG_BASIC) {
-                sample_add(p, sample, slot, w * material_color(s, m, h.u, h.v));
+                sample_term(p, sample, slot, w * material_color(s, m, h.u, h.v));
             } else {
                 double trans = sample_scalar(s, m.transparency_fn, m.transparency, h.u, h.v);
                 double smooth = sample_scalar(s, m.smoothness_fn, m.smoothness, h.u, h.v);
@@ -1217,7 +1279,7 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
                 bool entering = is_entering(h.normal, inv_dir);
                 d3 emission = ld3(m.emission);
                 if (!(emission.x == 0.0 && emission.y == 0.0 && emission.z == 0.0)) {
-                    sample_add(p, sample, slot, w * emission);
+                    sample_term(p, sample, slot, w * emission);
                 } else {
                     double ni = sample_scalar(s, m.ni_fn, m.ni, h.u, h.v);
                     d3 dir, pos;
@@ -1257,7 +1319,7 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
                         cw = w * (spec + (kD * diffuse));
                     }
                     cbranch = rng.branch; ccounter = rng.counter;
-                    if (layer + 1 > p.d.max_depth) sample_add(p, sample, slot, cw * (clear * 0.1));   // :220-222
+                    if (layer + 1 > p.d.max_depth) sample_term(p, sample, slot, cw * (clear * 0.1));  // :220-222
                     else spawn = true;
                 }
             }
@@ -1285,7 +1347,7 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
     if (i < n) {
         int32_t prim = q.hit_prim[i];
         if (prim < 0) {
-            sample_add(p, sample, queue_slot(p, q, i), queue_weight(p, q, i) * ld3(p.d.clear_color));
+            sample_term(p, sample, queue_slot(p, q, i), queue_weight(p, q, i) * ld3(p.d.clear_color));
         } else {
             hit = true;
         }
@@ -1352,6 +1414,7 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
     double ni = 1.0; uint32_t slot = 0, branch = 0, counter = 0;
     const uint32_t layer = p.layer;
     if (i < n && q.hit_prim[i] >= 0) {
+        d3 sum = mk(0.0, 0.0, 0.0);
         slot = queue_slot(p, q, i); branch = p.camera_queue ? 0u : q.branch[i]; counter = q.counter[i];
         d3 w = queue_weight(p, q, i);
         d3 clear = ld3(p.d.clear_color);
@@ -1416,10 +1479,10 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
             d3 pos = h.position + ((h.normal * (entering ? -1.0 : 1.0)) * p.d.bias);
             child_t = make_ray(pos, dir);
             wt = w * wtrans;
-            if (layer + 1 > p.d.max_depth) sample_add(p, sample, slot, wt * clear);    // :456-460
+            if (layer + 1 > p.d.max_depth) sample_term(p, sample, slot, wt * clear, sum);  // :456-460
             else spawn_t = true;
         } else {
-            sample_add(p, sample, slot, w * (clear * wtrans));  // transparentRayResult stays clearColor (:532)
+            sample_term(p, sample, slot, w * (clear * wtrans), sum);    // transparentRayResult stays clearColor (:532)
         }
         double wl = 1.0 - trans;
         if (p.d.flags & RTX_FLAG_WHITTED_REFLECT) {
@@ -1427,12 +1490,13 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
             if (smooth != 0.0) {
                 child_r = make_ray(h.position + (h.normal * p.d.bias), mirror_direction(d, h.normal));
                 wr = w * (smooth * wl);
-                if (layer + 1 > p.d.max_depth) sample_add(p, sample, slot, wr * clear);
+                if (layer + 1 > p.d.max_depth) sample_term(p, sample, slot, wr * clear, sum);
                 else spawn_r = true;
                 wl = wl * (1.0 - smooth);
             }
         }
-        sample_add(p, sample, slot, w * (local * wl));
+        sample_term(p, sample, slot, w * (local * wl), sum);
+        if (p.direct_store) sample_store(p, sample, slot, sum);
     }
     __shared__ uint32_t reserve_lds[kBlock / 64 + 2];
     uint32_t jt = block_reserve(spawn_t, next_count, 1, reserve_lds);
@@ -1449,25 +1513,13 @@ k_resolve(RenderParams p, const double* __restrict__ sample, float* accum)
 {
     uint32_t k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= p.chunk_pixels) return;
-    uint32_t x, y;
-    pixel_of(p, p.chunk_t0 + k, x, y);
     uint32_t nn = p.n * p.n;
     d3 acum = mk(0, 0, 0);
     for (uint32_t sub = 0; sub < nn; ++sub) {
         const double* sp = sample + 3 * ((size_t)k * nn + sub);
         acum = acum + mk(sp[0], sp[1], sp[2]);
     }
-    d3 px = acum / (double)nn;
-    size_t at = 3 * ((size_t)(x - p.d.tile_x0) + (size_t)(y - p.d.tile_y0) * p.d.tile_w);
-    if (p.overwrite) {      // 0.0f + float(px): what adding to a cleared buffer gives
-        accum[at + 0] = 0.0f + (float)px.x;
-        accum[at + 1] = 0.0f + (float)px.y;
-        accum[at + 2] = 0.0f + (float)px.z;
-    } else {
-        accum[at + 0] += (float)px.x;
-        accum[at + 1] += (float)px.y;
-        accum[at + 2] += (float)px.z;
-    }
+    resolve_pixel(p, k, acum, accum);
 }
 
 // Ray totals of one level (one thread), so that the host need not read the per-level counters:

@@ -273,6 +273,48 @@ def test_computed_camera_rays_equal_stored_ones(gpu, monkeypatch, kind):
             assert np.isfinite(a).all() and a.max() > 0
 
 
+@pytest.mark.parametrize("kind", ["path", "path_1spp", "basic", "whitted_soft", "whitted_1spp", "whitted_refract", "gather"])
+def test_stored_samples_equal_accumulated_ones(gpu, monkeypatch, kind):
+    """A sample slot whose whole value comes from one thread is stored once (with one sub-sample
+    per pixel: written to the framebuffer at once, no resolve launch); RTX_FLAG_ACCUMULATE_SAMPLES
+    clears the slots, adds every term and resolves.  Same bits, over chunks, passes, tiles that
+    are added to or overwritten, and with stored camera rays too."""
+    flags = 0
+    if kind in ("path", "path_1spp", "basic"):
+        scene, cam = scenes.lens_scene()
+        kw = dict(integrator=abi.INTEGRATOR_PATH, n=1 if kind == "path_1spp" else 2, max_depth=8, bias=1e-4, passes=3)
+        flags = abi.FLAG_BASIC if kind == "basic" else 0
+    elif kind in ("whitted_soft", "whitted_1spp"):
+        scene, cam = scenes.mesh_scene(slices=60, stacks=30, ggx=True, square_light=True)
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=1 if kind == "whitted_1spp" else 2, max_depth=3, bias=1e-2,
+                  light_n=2, passes=2)
+    elif kind == "whitted_refract":       # children: terms of a slot come from several launches, nothing is stored
+        scene, cam = scenes.whitted_scene()
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=1, max_depth=4)
+    else:
+        scene, cam = scenes.mesh_scene(slices=40, stacks=20)
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=1, max_depth=2, global_samples=4)
+        flags = abi.FLAG_GLOBAL_LIGHTING
+    desc = scene.frame(0.2)
+    monkeypatch.setenv("RTX_TWO_LANE_MIN", "128")
+    monkeypatch.setenv("RTX_MAX_PATHS", "8192")
+    with gpu.DeviceScene(desc) as ds:
+        for extra in (0, abi.FLAG_OVERWRITE, abi.FLAG_STORE_CAMERA_RAYS):
+            junk = np.full((90, 150, 3), 0.25, np.float32)
+            a, sa = ds.render(scenes.render_desc(150, 90, camera=cam, flags=flags | extra, **kw), accum=junk.copy())
+            b, sb = ds.render(scenes.render_desc(150, 90, camera=cam, flags=flags | extra | abi.FLAG_ACCUMULATE_SAMPLES, **kw),
+                              accum=junk.copy())
+            _same_ray_counts(sa, sb)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), extra
+            assert np.isfinite(a).all() and a.max() > 0.25
+        # a tile inside a larger frame
+        rd = scenes.render_desc(150, 90, camera=cam, flags=flags, tile=(40, 24, 70, 50), **kw)
+        a, _ = ds.render(rd)
+        rd.flags |= abi.FLAG_ACCUMULATE_SAMPLES
+        b, _ = ds.render(rd)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_overwrite_flag_equals_cleared_buffer(gpu):
     """RTX_FLAG_OVERWRITE: the first pass stores, later passes add; a buffer full of other
     values gives the image a cleared buffer gives."""

@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--sort-material", action="store_true", help="shade pathTrace levels in material order")
     ap.add_argument("--refill-lanes", action="store_true", help="BVH walk with finished lanes refilled from the queue")
     ap.add_argument("--store-camera-rays", action="store_true", help="camera rays written by a generate kernel and read back")
+    ap.add_argument("--accumulate-samples", action="store_true", help="sample slots cleared, added to and resolved")
     ap.add_argument("--serial", action="store_true", help="one chunk at a time on the caller's stream (no two-lane overlap)")
     ap.add_argument("--no-stage-times", action="store_true", help="no per-stage events (their gaps cost time on short frames)")
     ap.add_argument("--in-flight", type=int, default=1,
@@ -105,6 +106,7 @@ def main():
             rd.flags |= abi.FLAG_SERIAL_CHUNKS if args.serial else 0
             rd.flags |= abi.FLAG_REFILL_LANES if args.refill_lanes else 0
             rd.flags |= abi.FLAG_STORE_CAMERA_RAYS if args.store_camera_rays else 0
+            rd.flags |= abi.FLAG_ACCUMULATE_SAMPLES if args.accumulate_samples else 0
             st = ds.render_device(rd, fb.data_ptr())
             for k in rays:
                 rays[k] += getattr(st, k)
