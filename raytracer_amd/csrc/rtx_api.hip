@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -49,18 +50,37 @@ int fail(int code, const char* fmt, ...)
 
 struct DeviceBuffers {
     std::vector<void*> ptrs;
-    ~DeviceBuffers() { for (void* p : ptrs) (void)hipFree(p); }
+    // Copies go through a non-blocking stream of their own: a copy on the default stream would
+    // wait for every kernel the process has in flight, and a scene is typically uploaded while
+    // the previous frame still renders.  finish() waits for the copies and gives the stream back.
+    hipStream_t copy_stream = nullptr;
+    ~DeviceBuffers()
+    {
+        (void)finish();
+        for (void* p : ptrs) (void)hipFree(p);
+    }
     template <class T>
     hipError_t upload(const T* host, size_t count, const T** out)
     {
         *out = nullptr;
         if (count == 0) return hipSuccess;
+        hipError_t e = hipSuccess;
+        if (!copy_stream) e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, count * sizeof(T));
+        e = hipMalloc(&p, count * sizeof(T));
         if (e != hipSuccess) return e;
         ptrs.push_back(p);
-        e = hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice);
+        e = hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, copy_stream);
         *out = static_cast<const T*>(p);
+        return e;
+    }
+    hipError_t finish()
+    {
+        if (!copy_stream) return hipSuccess;
+        hipError_t e = hipStreamSynchronize(copy_stream);
+        (void)hipStreamDestroy(copy_stream);
+        copy_stream = nullptr;
         return e;
     }
 };
@@ -365,6 +385,18 @@ inline dim3 trace_grid_for(size_t n) { return dim3((unsigned)((n + kTraceBlock -
 
 }  // namespace
 
+// fn(lo, hi) over [0, n) in a few contiguous pieces, each on a thread of its own
+template <class F>
+static void in_pieces(uint32_t n, F fn)
+{
+    const uint32_t pieces = n < (1u << 16) ? 1u : 4u;
+    std::vector<std::future<void>> rest;
+    for (uint32_t k = 1; k < pieces; ++k)
+        rest.push_back(std::async(std::launch::async, fn, (uint32_t)((uint64_t)n * k / pieces), (uint32_t)((uint64_t)n * (k + 1) / pieces)));
+    fn(0u, n / pieces);
+    for (auto& f : rest) f.get();
+}
+
 extern "C" {
 
 const char* rtx_last_error(void) { return g_error.c_str(); }
@@ -400,6 +432,16 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     if (rc != RTX_OK) return rc;
     if (rtx_device_count() <= 0) return fail(RTX_ERR_NO_GPU, "no HIP device is visible");
 
+    // RTX_TIMINGS=1: the host stages of this call, in milliseconds, on stderr
+    const bool timings = std::getenv("RTX_TIMINGS") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timings) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "rtx_scene_create: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    lap("validate");
     rtx_scene* sc = new rtx_scene();
     sc->kd_depth = kd_depth;
     (void)hipGetDevice(&sc->device);
@@ -443,23 +485,89 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     for (uint32_t i = 0; i < s->n_materials; ++i)
         if (s->materials[i].transparency != 0.0 || s->materials[i].transparency_fn.kind != RTX_SAMPLER_CONST) sc->may_refract = true;
     for (uint32_t i = 0; i < s->n_lights; ++i) sc->light_multisample.push_back(s->lights[i].multisample ? 1 : 0);
+    lap("copy branches, boxes");
     BvhBuild bvh;
-    std::future<void> bvh_done = std::async(std::launch::async, [&]() { build_bvh(boxes, s->n_shapes, bvh); });
+    std::vector<BvhPrim> bvh_prims;
+    std::future<void> bvh_done = std::async(std::launch::async, [&]() {
+        build_bvh(boxes, s->n_shapes, bvh);
+        bvh_prims.resize(bvh.prims.size());
+        for (size_t i = 0; i < bvh.prims.size(); ++i) {
+            BvhPrim& q = bvh_prims[i];
+            std::memset(&q, 0, sizeof q);
+            q.shape = bvh.prims[i];
+            q.info = info[q.shape];
+            if ((q.info & 3u) == RTX_PRIM_TRIANGLE) std::memcpy(q.p, s->tri_position + 9 * (size_t)(q.info >> 2), sizeof q.p);
+        }
+    });
     struct Join { std::future<void>& f; ~Join() { if (f.valid()) f.wait(); } } join_bvh{bvh_done};
+
+    const double big = std::numeric_limits<double>::max();
+    // Three derivations that do not depend on one another run side by side: the inverse leaf
+    // index and the leaf cells on threads of their own, the content boxes and leaf-id ranges here.
+    // (The cells read the branches' boxes and planes only, the ranges are other members.)
+    // inverse leaf index: for every shape the leaves that reference it, in increasing order
+    std::vector<uint32_t> prim_leaf_first(s->n_shapes + 1, 0), prim_leaf_ids(s->n_leaf_refs), prim_leaf_pos(s->n_leaf_refs);
+    std::future<void> inverse_done = std::async(std::launch::async, [&]() {
+        for (uint32_t r = 0; r < s->n_leaf_refs; ++r) prim_leaf_first[s->leaf_refs[r] + 1]++;
+        for (uint32_t p = 0; p < s->n_shapes; ++p) prim_leaf_first[p + 1] += prim_leaf_first[p];
+        std::vector<uint32_t> cursor(prim_leaf_first.begin(), prim_leaf_first.end() - 1);
+        for (uint32_t leaf = 0; leaf < s->n_leaves; ++leaf)
+            for (uint32_t r = 0; r < s->leaf_count[leaf]; ++r) {
+                uint32_t pos = s->leaf_first[leaf] + r, p = s->leaf_refs[pos];
+                // a shape listed twice in one leaf keeps its first position
+                if (cursor[p] > prim_leaf_first[p] && prim_leaf_ids[cursor[p] - 1] == leaf) continue;
+                prim_leaf_ids[cursor[p]] = leaf; prim_leaf_pos[cursor[p]] = pos; cursor[p]++;
+            }
+        // compact away slots left by duplicates
+        bool dup = false;
+        for (uint32_t p = 0; p < s->n_shapes; ++p) if (cursor[p] != prim_leaf_first[p + 1]) dup = true;
+        if (dup) {
+            std::vector<uint32_t> nf(s->n_shapes + 1, 0), ni, np;
+            for (uint32_t p = 0; p < s->n_shapes; ++p) {
+                for (uint32_t k = prim_leaf_first[p]; k < cursor[p]; ++k) { ni.push_back(prim_leaf_ids[k]); np.push_back(prim_leaf_pos[k]); }
+                nf[p + 1] = (uint32_t)ni.size();
+            }
+            prim_leaf_first.swap(nf); prim_leaf_ids.swap(ni); prim_leaf_pos.swap(np);
+        }
+    });
+    struct Join2 { std::future<void>& f; ~Join2() { if (f.valid()) f.wait(); } } join_inverse{inverse_done};
+    // leaf cells for member_by_cell()
+    std::vector<PrimBox> leaf_cell(s->n_leaves);
+    std::future<void> cells_done = std::async(std::launch::async, [&]() {
+        PrimBox all;
+        for (int k = 0; k < 3; ++k) { all.bmin[k] = -big; all.bmax[k] = big; }
+        std::vector<std::pair<int32_t, PrimBox>> st;
+        st.push_back({s->kd_root, all});
+        while (!st.empty()) {
+            auto [node, cell] = st.back();
+            st.pop_back();
+            if (node < 0) { leaf_cell[(uint32_t)~node] = cell; continue; }
+            const Branch& b = branches[node];
+            for (int k = 0; k < 3; ++k) { cell.bmin[k] = std::max(cell.bmin[k], b.bmin[k]); cell.bmax[k] = std::min(cell.bmax[k], b.bmax[k]); }
+            PrimBox lo = cell, hi = cell;
+            lo.bmax[b.axis] = std::min(lo.bmax[b.axis], b.value);
+            hi.bmin[b.axis] = std::max(hi.bmin[b.axis], b.value);
+            st.push_back({b.lesser, lo});
+            st.push_back({b.greater, hi});
+        }
+    });
+    Join2 join_cells{cells_done};
 
     // content boxes for the culled walk: per leaf the union of its shape boxes, per branch
     // the union of its children's (an empty leaf gets an inverted box that no ray hits)
     std::vector<PrimBox> leaf_cbox(s->n_leaves), branch_cbox(s->n_branches);
-    const double big = std::numeric_limits<double>::max();
     auto grow = [](PrimBox& a, const PrimBox& b) {
         for (int k = 0; k < 3; ++k) { a.bmin[k] = std::min(a.bmin[k], b.bmin[k]); a.bmax[k] = std::max(a.bmax[k], b.bmax[k]); }
     };
-    for (uint32_t i = 0; i < s->n_leaves; ++i) {
-        PrimBox c;
-        for (int k = 0; k < 3; ++k) { c.bmin[k] = big; c.bmax[k] = -big; }
-        for (uint32_t r = 0; r < s->leaf_count[i]; ++r) grow(c, boxes[s->leaf_refs[s->leaf_first[i] + r]]);
-        leaf_cbox[i] = c;
-    }
+    in_pieces(s->n_leaves, [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; ++i) {
+            PrimBox c;
+            for (int k = 0; k < 3; ++k) { c.bmin[k] = big; c.bmax[k] = -big; }
+            for (uint32_t r = 0; r < s->leaf_count[i]; ++r) grow(c, boxes[s->leaf_refs[s->leaf_first[i] + r]]);
+            leaf_cbox[i] = c;
+        }
+    });
+    lap("leaf content boxes");
     std::vector<uint32_t> leaf_lo(s->n_branches, 0);
     {
         // children before parents: explicit post-order walk (the tree was validated above)
@@ -497,51 +605,10 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
             return fail(RTX_ERR_INVALID, "KD leaves are not numbered in walk order (branch %u)", i);
         }
     }
-    // inverse leaf index: for every shape the leaves that reference it, in increasing order
-    std::vector<uint32_t> prim_leaf_first(s->n_shapes + 1, 0), prim_leaf_ids(s->n_leaf_refs), prim_leaf_pos(s->n_leaf_refs);
-    for (uint32_t r = 0; r < s->n_leaf_refs; ++r) prim_leaf_first[s->leaf_refs[r] + 1]++;
-    for (uint32_t p = 0; p < s->n_shapes; ++p) prim_leaf_first[p + 1] += prim_leaf_first[p];
-    {
-        std::vector<uint32_t> cursor(prim_leaf_first.begin(), prim_leaf_first.end() - 1);
-        for (uint32_t leaf = 0; leaf < s->n_leaves; ++leaf)
-            for (uint32_t r = 0; r < s->leaf_count[leaf]; ++r) {
-                uint32_t pos = s->leaf_first[leaf] + r, p = s->leaf_refs[pos];
-                // a shape listed twice in one leaf keeps its first position
-                if (cursor[p] > prim_leaf_first[p] && prim_leaf_ids[cursor[p] - 1] == leaf) continue;
-                prim_leaf_ids[cursor[p]] = leaf; prim_leaf_pos[cursor[p]] = pos; cursor[p]++;
-            }
-        // compact away slots left by duplicates
-        bool dup = false;
-        for (uint32_t p = 0; p < s->n_shapes; ++p) if (cursor[p] != prim_leaf_first[p + 1]) dup = true;
-        if (dup) {
-            std::vector<uint32_t> nf(s->n_shapes + 1, 0), ni, np;
-            for (uint32_t p = 0; p < s->n_shapes; ++p) {
-                for (uint32_t k = prim_leaf_first[p]; k < cursor[p]; ++k) { ni.push_back(prim_leaf_ids[k]); np.push_back(prim_leaf_pos[k]); }
-                nf[p + 1] = (uint32_t)ni.size();
-            }
-            prim_leaf_first.swap(nf); prim_leaf_ids.swap(ni); prim_leaf_pos.swap(np);
-        }
-    }
-    // leaf cells and per-shape covering nodes for member_by_cell()
-    std::vector<PrimBox> leaf_cell(s->n_leaves);
-    {
-        PrimBox all;
-        for (int k = 0; k < 3; ++k) { all.bmin[k] = -big; all.bmax[k] = big; }
-        std::vector<std::pair<int32_t, PrimBox>> st;
-        st.push_back({s->kd_root, all});
-        while (!st.empty()) {
-            auto [node, cell] = st.back();
-            st.pop_back();
-            if (node < 0) { leaf_cell[(uint32_t)~node] = cell; continue; }
-            const Branch& b = branches[node];
-            for (int k = 0; k < 3; ++k) { cell.bmin[k] = std::max(cell.bmin[k], b.bmin[k]); cell.bmax[k] = std::min(cell.bmax[k], b.bmax[k]); }
-            PrimBox lo = cell, hi = cell;
-            lo.bmax[b.axis] = std::min(lo.bmax[b.axis], b.value);
-            hi.bmin[b.axis] = std::max(hi.bmin[b.axis], b.value);
-            st.push_back({b.lesser, lo});
-            st.push_back({b.greater, hi});
-        }
-    }
+    lap("branch content boxes, ranges");
+    inverse_done.get();
+    cells_done.get();
+    lap("wait for index and cells");
     std::vector<KdSplit> kd_split(s->n_branches);
     for (uint32_t i = 0; i < s->n_branches; ++i) {
         kd_split[i].value = branches[i].value;
@@ -549,27 +616,23 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
         kd_split[i].greater = branches[i].greater;
     }
     std::vector<int32_t> prim_lca(s->n_shapes, s->kd_root);
-    for (uint32_t p = 0; p < s->n_shapes; ++p) {
-        if (prim_leaf_first[p] == prim_leaf_first[p + 1]) continue;      // in no leaf: never looked up
-        const uint32_t lo = prim_leaf_ids[prim_leaf_first[p]], hi = prim_leaf_ids[prim_leaf_first[p + 1] - 1];
-        int32_t node = s->kd_root;
-        while (node >= 0) {
-            const Branch& b = branches[node];
-            if (hi < b.leaf_mid) node = b.lesser;
-            else if (lo >= b.leaf_mid) node = b.greater;
-            else break;
+    in_pieces(s->n_shapes, [&](uint32_t first, uint32_t last) {
+        for (uint32_t p = first; p < last; ++p) {
+            if (prim_leaf_first[p] == prim_leaf_first[p + 1]) continue;      // in no leaf: never looked up
+            const uint32_t lo = prim_leaf_ids[prim_leaf_first[p]], hi = prim_leaf_ids[prim_leaf_first[p + 1] - 1];
+            int32_t node = s->kd_root;
+            while (node >= 0) {
+                const Branch& b = branches[node];
+                if (hi < b.leaf_mid) node = b.lesser;
+                else if (lo >= b.leaf_mid) node = b.greater;
+                else break;
+            }
+            prim_lca[p] = node;
         }
-        prim_lca[p] = node;
-    }
+    });
+    lap("kd_split, prim_lca");
     bvh_done.get();
-    std::vector<BvhPrim> bvh_prims(bvh.prims.size());
-    for (size_t i = 0; i < bvh.prims.size(); ++i) {
-        BvhPrim& q = bvh_prims[i];
-        std::memset(&q, 0, sizeof q);
-        q.shape = bvh.prims[i];
-        q.info = info[q.shape];
-        if ((q.info & 3u) == RTX_PRIM_TRIANGLE) std::memcpy(q.p, s->tri_position + 9 * (size_t)(q.info >> 2), sizeof q.p);
-    }
+    lap("wait for the BVH");
     d.bvh_root = bvh.root;
     sc->bvh_depth = (uint32_t)bvh.depth;
     double scale = 0.0;
@@ -577,6 +640,7 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
         for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(b.bmin[k]), std::fabs(b.bmax[k])));
     d.scene_scale = scale;
 
+    lap("bvh_prims, scale");
     sc->buffers = std::make_shared<DeviceBuffers>();
     DeviceBuffers& B = *sc->buffers;
     hipError_t e = hipSuccess;
@@ -610,10 +674,13 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     up(s->textures, (size_t)s->n_textures, &d.textures);
     up(s->texels, (size_t)s->n_texel_bytes, &d.texels);
     up(s->lights, (size_t)s->n_lights, &d.lights);
+    // the host arrays (the caller's and the tables above) are read until here
+    { hipError_t done = B.finish(); if (e == hipSuccess) e = done; }
     if (e != hipSuccess) {
         delete sc;
         return fail(RTX_ERR_DEVICE, "scene upload: %s", hipGetErrorString(e));
     }
+    lap("upload");
     *out = sc;
     return RTX_OK;
 }
