@@ -52,34 +52,48 @@ struct Builder {
         const int nextAxis = (axis + 1) % 3;
 
         // lesser list: shapes with min <= value in the order (min, incoming position)
-        std::vector<Rec> rec;
-        rec.reserve(n);
-        for (size_t i = 0; i < n; ++i) {
-            double m = t.mn[3 * (size_t)ids[i] + axis];
-            if (m <= value) rec.push_back({m, 0.0, (uint32_t)i, ids[i]});
-        }
-        std::sort(rec.begin(), rec.end(), recLess);
-        std::vector<uint32_t> lesserIds(rec.size());
-        for (size_t i = 0; i < rec.size(); ++i) lesserIds[i] = rec[i].id;
-
+        std::vector<uint32_t> lesserIds;
+        auto makeLesser = [&]() {
+            std::vector<Rec> rec;
+            rec.reserve(n);
+            for (size_t i = 0; i < n; ++i) {
+                double m = t.mn[3 * (size_t)ids[i] + axis];
+                if (m <= value) rec.push_back({m, 0.0, (uint32_t)i, ids[i]});
+            }
+            std::sort(rec.begin(), rec.end(), recLess);
+            lesserIds.resize(rec.size());
+            for (size_t i = 0; i < rec.size(); ++i) lesserIds[i] = rec[i].id;
+        };
         // greater list: order (max, min, incoming position); the shapes with max >= value and,
         // unless that is all of them, the last shape below the split value in that order
-        rec.clear();
-        bool haveExtra = false;
-        Rec extra{0.0, 0.0, 0u, 0u};
-        for (size_t i = 0; i < n; ++i) {
-            Rec r{t.mx[3 * (size_t)ids[i] + axis], t.mn[3 * (size_t)ids[i] + axis], (uint32_t)i, ids[i]};
-            if (r.k1 >= value) rec.push_back(r);
-            else if (!haveExtra || recLess(extra, r)) { extra = r; haveExtra = true; }
-        }
         std::vector<uint32_t> greaterIds;
-        if (!rec.empty()) {
-            std::sort(rec.begin(), rec.end(), recLess);
-            greaterIds.reserve(rec.size() + 1);
-            if (haveExtra) greaterIds.push_back(extra.id);
-            for (const Rec& r : rec) greaterIds.push_back(r.id);
+        auto makeGreater = [&]() {
+            std::vector<Rec> rec;
+            rec.reserve(n);
+            bool haveExtra = false;
+            Rec extra{0.0, 0.0, 0u, 0u};
+            for (size_t i = 0; i < n; ++i) {
+                Rec r{t.mx[3 * (size_t)ids[i] + axis], t.mn[3 * (size_t)ids[i] + axis], (uint32_t)i, ids[i]};
+                if (r.k1 >= value) rec.push_back(r);
+                else if (!haveExtra || recLess(extra, r)) { extra = r; haveExtra = true; }
+            }
+            if (!rec.empty()) {
+                std::sort(rec.begin(), rec.end(), recLess);
+                greaterIds.reserve(rec.size() + 1);
+                if (haveExtra) greaterIds.push_back(extra.id);
+                for (const Rec& r : rec) greaterIds.push_back(r.id);
+            }
+        };
+        // the two lists do not depend on each other: near the root, where a node's sorts are
+        // the longest serial stretches of the build, they are made side by side
+        if (layer < spawnLayers && n >= 4096) {
+            auto fut = std::async(std::launch::async, makeLesser);
+            makeGreater();
+            fut.get();
+        } else {
+            makeLesser();
+            makeGreater();
         }
-        std::vector<Rec>().swap(rec);
         std::vector<uint32_t>().swap(ids);
 
         const uint32_t me = (uint32_t)out.value.size();
