@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <future>
 #include <stdexcept>
 #include <unordered_map>
 
@@ -342,6 +343,14 @@ struct Flattener {
 
     void run(const AABB* sceneBox, int threads) {
         const uint32_t nShapes = (uint32_t)fi.shapes.size();
+        // The tree is built from the shapes' boxes alone, the arrays below from everything else:
+        // the two go side by side (the builder's own threads are busy for a part of its run only).
+        FlatKD kd;
+        std::future<void> kdDone;
+        if (sceneBox) kdDone = std::async(std::launch::async, [&]() { buildFlatKD(fi.shapes, *sceneBox, kd, threads); });
+        out.triPos.reserve(9 * (size_t)nShapes); out.triNrm.reserve(9 * (size_t)nShapes); out.triUv.reserve(6 * (size_t)nShapes);
+        out.primType.reserve(nShapes); out.primIndex.reserve(nShapes); out.primMaterial.reserve(nShapes);
+        out.primMin.reserve(3 * (size_t)nShapes); out.primMax.reserve(3 * (size_t)nShapes);
         std::vector<const Biconvex*> lenses;
         for (uint32_t i = 0; i < nShapes; ++i) {
             const Shape* s = fi.shapes[i];
@@ -372,8 +381,7 @@ struct Flattener {
         }
         for (const Light* l : fi.lights) out.lights.push_back(l->flatten());
         if (sceneBox) {
-            FlatKD kd;
-            buildFlatKD(fi.shapes, *sceneBox, kd, threads);
+            kdDone.get();
             out.branchMin.swap(kd.bmin); out.branchMax.swap(kd.bmax); out.branchValue.swap(kd.value);
             out.branchAxis.swap(kd.axis); out.branchLesser.swap(kd.lesser); out.branchGreater.swap(kd.greater);
             out.leafFirst.swap(kd.leafFirst); out.leafCount.swap(kd.leafCount); out.leafRefs.swap(kd.leafRefs);
