@@ -258,7 +258,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "k_trace (KD traversal + leaf scans), primary and shadow launches",
+                "kernel": {"bvh": "k_trace_pool<false,3> (primary) and <false,4> (shadow): BVH candidates + KD membership verification",
+                           "kd-culled": "k_trace_pool<false,1> (primary) and <false,2> (shadow): culled walk of the reference's KD tree",
+                           "reference": "k_trace_pool<false,0>: the reference's KD walk, node for node"}[args.walk],
                 "algorithmic_bytes_per_ray": round(alg_bytes / max(rays, 1), 1),
                 "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
                 # two half-frame chunks run on two streams: a launch shares the machine with the other
