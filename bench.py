@@ -299,7 +299,7 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
     scene, _ = scenes.mesh_scene(ggx=True, square_light=True)
     desc = scene.frame(0.0)
     ds = device.DeviceScene(desc, stream=stream)
-    # the rank's four bands are queued on four streams, each through its own handle on the scene
+    # the rank's bands are queued round-robin on four streams, each through its own handle on the scene
     B = int(os.environ.get("BENCH_BAND_STREAMS", "4"))
     streams = [torch.cuda.Stream() for _ in range(B)]
     handles = [ds.clone(stream=st.cuda_stream) for st in streams]
@@ -307,6 +307,11 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
         h.set_async(True)
     rays = [0]
     fl = abi.FLAG_SERIAL_CHUNKS if os.environ.get("BENCH_BAND_SERIAL", "1") == "1" else 0
+    # Interleaved bands of equal height, 96 over all ranks (four on one GPU, where nothing needs
+    # balancing): the mesh fills the middle rows, and the slowest rank's share sets the frame time.
+    # One rank's share of an 8-rank frame, timed on one GPU: 3.38 ms with 4 bands per rank, 2.82 ms
+    # with 12 (19.1 / 8 = 2.39 ms); finer bands lose more to short launches than they balance.
+    bands_per_rank = 4 if world == 1 else max(4, 96 // world)
 
     def one_frame(f):
         cam = scenes.orbit_camera(f / 30.0)
@@ -325,8 +330,7 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
         def after_bands():
             for k in range(B):
                 rays[0] += handles[k].wait().rays
-        # four interleaved bands of equal height per rank
-        return rdist.render_frame_bands(render_rect, W, H, dev, bands_per_rank=4, after_bands=after_bands,
+        return rdist.render_frame_bands(render_rect, W, H, dev, bands_per_rank=bands_per_rank, after_bands=after_bands,
                                         comm_device=None if comm_dev == dev else comm_dev)
 
     def sync():
@@ -352,8 +356,8 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
         h.close()
     ds.close()
     return {"workload": "configs[3]: GGX-parameter mesh, texture + checker floor, SquareLight 2x2 samples, 1080p 16 spp, "
-                        f"whitted; one frame in {4 * world} interleaved bands of equal height, four per rank, "
-                        f"queued on {B} streams",
+                        f"whitted; one frame in {bands_per_rank * world} interleaved bands of equal height, "
+                        f"{bands_per_rank} per rank, queued on {B} streams",
             "ms_per_frame": round(dt / frames * 1e3, 3), "Mrays_per_s": round(tt[1].item() / dt / 1e6, 1),
             "frames": frames, "n_gpus": world, "scaling": "strong"}
 
