@@ -181,6 +181,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         step_fn(args.warmup + s, abi.FLAG_TRACE_TIMES)      # HIP events around the traversal launches only
+    queued_s = time.perf_counter() - t0                     # host time to queue the steps
     drain()
     totals = [h.wait() for h in handles]        # statistics summed over each handle's frames
     sync()
@@ -255,6 +256,7 @@ def main():
             },
             "rays_per_frame": total_rays / frames,
             "ms_per_frame": round(elapsed / frames * 1e3, 4),       # sequence throughput: all ranks' frames
+            "host_ms_per_step": round(queued_s / args.steps * 1e3, 4),   # rank 0's host time to queue one step
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
