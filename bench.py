@@ -301,39 +301,24 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
     scene, _ = scenes.mesh_scene(ggx=True, square_light=True)
     desc = scene.frame(0.0)
     ds = device.DeviceScene(desc, stream=stream)
-    # the rank's bands are queued round-robin on four streams, each through its own handle on the scene
-    B = int(os.environ.get("BENCH_BAND_STREAMS", "4"))
-    streams = [torch.cuda.Stream() for _ in range(B)]
-    handles = [ds.clone(stream=st.cuda_stream) for st in streams]
-    for h in handles:
-        h.set_async(True)
+    # Every rank renders its share of the frame -- the groups of 8 rows g with g % world == rank,
+    # one tile of interleaved rows (tile_row_group / tile_row_stride) -- in ONE call, whose two
+    # chunks run on the library's two streams.  The mesh fills the middle rows and the slowest
+    # rank's share sets the frame time: groups of 8 rows balance the ranks to within a row group
+    # without cutting the work into many short launches.  (One rank's share of an 8-rank frame,
+    # timed on one GPU: 3.35 ms as 4 bands of rows, 2.78 ms as 12 bands, 2.62 ms this way;
+    # 19.1 / 8 = 2.39 ms.)
     rays = [0]
-    fl = abi.FLAG_SERIAL_CHUNKS if os.environ.get("BENCH_BAND_SERIAL", "1") == "1" else 0
-    # Interleaved bands of equal height, 96 over all ranks (four on one GPU, where nothing needs
-    # balancing): the mesh fills the middle rows, and the slowest rank's share sets the frame time.
-    # One rank's share of an 8-rank frame, timed on one GPU: 3.38 ms with 4 bands per rank, 2.82 ms
-    # with 12 (19.1 / 8 = 2.39 ms); finer bands lose more to short launches than they balance.
-    bands_per_rank = 4 if world == 1 else max(4, 96 // world)
 
     def one_frame(f):
         cam = scenes.orbit_camera(f / 30.0)
-        queued = [0]
-        start = torch.cuda.Event()
-        start.record()              # the zeroed band buffers
 
-        def render_rect(x0, y0, w, h, out):
+        def render_rows(y0, rows, group, stride, out):
             rd = scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=4, light_n=2, max_depth=3,
-                                    bias=1e-2, frame=f, tile=(x0, y0, w, h), flags=fl)
-            k = queued[0] % B
-            queued[0] += 1
-            streams[k].wait_event(start)
-            handles[k].render_device(rd, out.data_ptr())
-
-        def after_bands():
-            for k in range(B):
-                rays[0] += handles[k].wait().rays
-        return rdist.render_frame_bands(render_rect, W, H, dev, bands_per_rank=bands_per_rank, after_bands=after_bands,
-                                        comm_device=None if comm_dev == dev else comm_dev)
+                                    bias=1e-2, frame=f, tile=(0, y0, W, rows), row_group=group, row_stride=stride)
+            rays[0] += ds.render_device(rd, out.data_ptr()).rays
+        return rdist.render_frame_rows(render_rows, W, H, dev, group=8,
+                                       comm_device=None if comm_dev == dev else comm_dev)
 
     def sync():
         if world > 1:
@@ -354,12 +339,10 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt = mx[0].item()
-    for h in handles:
-        h.close()
     ds.close()
     return {"workload": "configs[3]: GGX-parameter mesh, texture + checker floor, SquareLight 2x2 samples, 1080p 16 spp, "
-                        f"whitted; one frame in {bands_per_rank * world} interleaved bands of equal height, "
-                        f"{bands_per_rank} per rank, queued on {B} streams",
+                        f"whitted; every rank renders its interleaved groups of 8 rows (group g to rank g % {world}) as one "
+                        "tile in one call, float rows gathered on rank 0",
             "ms_per_frame": round(dt / frames * 1e3, 3), "Mrays_per_s": round(tt[1].item() / dt / 1e6, 1),
             "frames": frames, "n_gpus": world, "scaling": "strong"}
 

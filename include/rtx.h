@@ -261,6 +261,13 @@ typedef struct rtx_render_desc {
                                        (Raytracer-Noah-Desktop.cpp:73): gather rays per light
                                        and hit at layer 0, divided by layer+1 below (:500);
                                        read only with RTX_FLAG_GLOBAL_LIGHTING             */
+    uint32_t tile_row_group;        /* 0: the tile's rows are consecutive frame rows.  Otherwise the
+                                       tile is every tile_row_stride-th group of tile_row_group rows:
+                                       tile row r is frame row
+                                         tile_y0 + (r / tile_row_group) * tile_row_stride + r % tile_row_group
+                                       (one rank's interleaved share of a frame in one call; accum
+                                       holds the tile's rows packed, tile_w * tile_h * 3 floats)  */
+    uint32_t tile_row_stride;       /* >= tile_row_group when that is not 0                   */
     uint32_t reserved;              /* 0 */
 } rtx_render_desc;
 

@@ -880,7 +880,8 @@ int orc_render(const rtx_scene_desc* s, const rtx_render_desc* d, float* accum, 
 #pragma omp for schedule(dynamic, 64)
             for (long long t = 0; t < npix; ++t) {
                 uint32_t x = d->tile_x0 + (uint32_t)(t % d->tile_w);
-                uint32_t y = d->tile_y0 + (uint32_t)(t / d->tile_w);
+                uint32_t row = (uint32_t)(t / d->tile_w);       /* tile rows may be interleaved groups of frame rows (rtx.h) */
+                uint32_t y = d->tile_y0 + (d->tile_row_group ? (row / d->tile_row_group) * d->tile_row_stride + row % d->tile_row_group : row);
                 v3 acum = V(0, 0, 0);
                 for (uint32_t sx = 1; sx <= n; ++sx)
                     for (uint32_t sy = 1; sy <= n; ++sy) {

@@ -122,7 +122,8 @@ class RenderDesc(C.Structure):
         ("frame", C.c_uint32), ("seed", C.c_uint64),
         ("bias", C.c_double), ("clear_color", D3), ("attenuation", D3),
         ("camera", Camera),
-        ("global_samples", C.c_uint32), ("reserved", C.c_uint32),
+        ("global_samples", C.c_uint32), ("tile_row_group", C.c_uint32), ("tile_row_stride", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

@@ -866,9 +866,15 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     if (!sc || !rd || !accum) return fail(RTX_ERR_INVALID, "null argument");
     if (rd->integrator > RTX_INTEGRATOR_WHITTED) return fail(RTX_ERR_INVALID, "unknown integrator");
     if (rd->width < 2 || rd->height < 2) return fail(RTX_ERR_INVALID, "frame must be at least 2x2");
-    if (rd->tile_w == 0 || rd->tile_h == 0 || rd->tile_x0 + (uint64_t)rd->tile_w > rd->width ||
-        rd->tile_y0 + (uint64_t)rd->tile_h > rd->height)
+    if (rd->tile_w == 0 || rd->tile_h == 0 || rd->tile_x0 + (uint64_t)rd->tile_w > rd->width)
         return fail(RTX_ERR_INVALID, "tile outside the frame");
+    {
+        // the frame row of the tile's last row (rows may be interleaved groups, see rtx.h)
+        const uint32_t g = rd->tile_row_group, last = rd->tile_h - 1;
+        if (g && rd->tile_row_stride < g) return fail(RTX_ERR_INVALID, "tile_row_stride below tile_row_group");
+        const uint64_t last_y = rd->tile_y0 + (g ? (uint64_t)(last / g) * rd->tile_row_stride + last % g : (uint64_t)last);
+        if (last_y >= rd->height) return fail(RTX_ERR_INVALID, "tile outside the frame");
+    }
     uint32_t n = rd->pixel_multisample_n ? rd->pixel_multisample_n : 1;
     if (n > 64) return fail(RTX_ERR_LIMIT, "pixel_multisample_n > 64");
     const bool whitted = rd->integrator == RTX_INTEGRATOR_WHITTED;

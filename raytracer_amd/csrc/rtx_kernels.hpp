@@ -679,7 +679,14 @@ RTX_DEV void pixel_of(const RenderParams& p, uint32_t t, uint32_t& x, uint32_t& 
     uint32_t wb = min(8u, W - 8u * bx);
     uint32_t ly = r2 / wb, lx = r2 - ly * wb;
     x = p.d.tile_x0 + bx * 8u + lx;
-    y = p.d.tile_y0 + band * 8u + ly;
+    const uint32_t row = band * 8u + ly;            // row of the tile
+    y = p.d.tile_y0 + (p.d.tile_row_group ? (row / p.d.tile_row_group) * p.d.tile_row_stride + row % p.d.tile_row_group : row);
+}
+// the tile row of frame row y (the inverse of the mapping above)
+RTX_DEV uint32_t tile_row_of(const RenderParams& p, uint32_t y)
+{
+    const uint32_t dy = y - p.d.tile_y0;
+    return p.d.tile_row_group ? (dy / p.d.tile_row_stride) * p.d.tile_row_group + dy % p.d.tile_row_stride : dy;
 }
 
 // The camera ray of sample slot `slot` of the chunk (Raytracer.cpp:676-700).
@@ -1121,7 +1128,7 @@ RTX_DEV void resolve_pixel(const RenderParams& p, uint32_t k, d3 acum, float* ac
     uint32_t x, y;
     pixel_of(p, p.chunk_t0 + k, x, y);
     d3 px = acum / (double)(p.n * p.n);
-    size_t at = 3 * ((size_t)(x - p.d.tile_x0) + (size_t)(y - p.d.tile_y0) * p.d.tile_w);
+    size_t at = 3 * ((size_t)(x - p.d.tile_x0) + (size_t)tile_row_of(p, y) * p.d.tile_w);
     if (p.overwrite) {
         accum[at + 0] = 0.0f + (float)px.x;
         accum[at + 1] = 0.0f + (float)px.y;

@@ -86,6 +86,63 @@ def render_frame_bands(render_rect, width, height, device, band_rows=64, group=N
     return frame
 
 
+def rank_rows(height, world, rank, group=8):
+    """Frame rows owned by `rank` when the frame is dealt out in groups of `group` rows, group g
+    to rank g % world: (first row, number of rows, stride between the rank's groups).  The rows
+    are first + (r // group) * stride + r % group for r in range(number): one tile with
+    tile_row_group = group, tile_row_stride = stride (rtx.h), rendered by one call."""
+    n_groups = (height + group - 1) // group
+    mine = len(range(rank, n_groups, world))
+    rows = mine * group
+    if mine and (rank + (mine - 1) * world) == n_groups - 1:      # this rank owns the last group, which may be short
+        rows -= n_groups * group - height
+    return rank * group, rows, world * group
+
+
+def render_frame_rows(render_rows, width, height, device, group=8, pg=None, comm_device=None, after=None):
+    """Render one frame cooperatively, every rank its interleaved groups of rows in ONE call.
+
+    render_rows(y0, rows, group, stride, out) must accumulate the float32 RGB of the tile
+    (0, y0, width, rows) with tile_row_group = group and tile_row_stride = stride into `out`
+    ([rows, width, 3] on `device`, zero-initialised here; packed rows).  Finer than bands and
+    without their many short launches: a rank's share is one tile of 1/world of the frame.
+    Returns the assembled [height, width, 3] frame on rank 0, None elsewhere.  `after()` is
+    called once the rank's work is queued and must make the current stream wait for it."""
+    world = dist.get_world_size(pg) if dist.is_initialized() else 1
+    rank = dist.get_rank(pg) if dist.is_initialized() else 0
+    most = max(rank_rows(height, world, r, group)[1] for r in range(world))
+    packed = torch.zeros((most, width, 3), dtype=torch.float32, device=device)
+    y0, rows, stride = rank_rows(height, world, rank, group)
+    if rows:
+        render_rows(y0, rows, group, stride, packed[:rows])
+    if after is not None:
+        after()
+    if comm_device is not None and torch.device(comm_device) != packed.device:
+        packed = packed.to(comm_device)
+    parts = _gather_to_rank0(packed, world, rank, pg)
+    if rank != 0:
+        return None
+    frame = torch.empty((height, width, 3), dtype=torch.float32, device=packed.device)
+    for r in range(world):
+        rows = rank_rows(height, world, r, group)[1]
+        if rows:        # one scatter of whole rows per rank
+            frame.index_copy_(0, _frame_rows(height, world, r, group, packed.device), parts[r][:rows])
+    return frame
+
+
+_row_index_cache = {}
+
+
+def _frame_rows(height, world, rank, group, device):
+    """The frame rows of `rank`'s packed rows, as an index tensor on `device` (kept between frames)."""
+    key = (height, world, rank, group, str(device))
+    if key not in _row_index_cache:
+        y0, rows, stride = rank_rows(height, world, rank, group)
+        k = torch.arange(rows, dtype=torch.int64)
+        _row_index_cache[key] = (y0 + (k // group) * stride + k % group).to(device)
+    return _row_index_cache[key]
+
+
 def render_sequence_frames(render_frame, n_frames, width, height, device, group=None):
     """Render frames 0..n_frames-1 round-robin.  render_frame(f, out) fills the [H, W, 3]
     float32 tensor `out`.  Rank 0 returns the list of all frames in order, others None."""

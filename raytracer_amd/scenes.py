@@ -15,13 +15,14 @@ from .host import HostScene, make_camera
 
 def render_desc(width, height, integrator=abi.INTEGRATOR_WHITTED, camera=None, n=1, light_n=1, max_depth=3,
                 bias=1e-3, clear=(0.0, 0.0, 0.0), flags=0, passes=1, first_pass=0, seed=0, frame=0, tile=None,
-                global_samples=0):
+                global_samples=0, row_group=0, row_stride=0):
     rd = abi.RenderDesc()
     rd.integrator = integrator
     rd.flags = flags
     rd.width, rd.height = width, height
     x0, y0, w, h = tile if tile is not None else (0, 0, width, height)
     rd.tile_x0, rd.tile_y0, rd.tile_w, rd.tile_h = x0, y0, w, h
+    rd.tile_row_group, rd.tile_row_stride = row_group, row_stride      # interleaved rows: see rtx.h
     rd.pixel_multisample_n = n
     rd.light_multisample_n = light_n
     rd.max_depth = max_depth

@@ -55,6 +55,16 @@ def _worker(rank, world, port, mode, out_path):
                                          bands_per_rank=3 if mode == "even-bands" else None)
         if rank == 0:
             np.save(out_path, frame.numpy())
+    elif mode == "rows":
+        def render_rows(y0, rows, group, stride, out):
+            from raytracer_amd import abi, scenes
+            rd = _rd(cam, tile=(0, y0, W, rows))
+            rd.tile_row_group, rd.tile_row_stride = group, stride
+            img, _, _, _ = orc.render(desc, rd, threads=2)
+            out += torch.from_numpy(img)
+        frame = rdist.render_frame_rows(render_rows, W, H, torch.device("cpu"), group=8)
+        if rank == 0:
+            np.save(out_path, frame.numpy())
     else:
         def render_frame(f, out):
             img, _, _, _ = orc.render(desc, _rd(cam, frame_t=f / 30.0), threads=2)
@@ -66,14 +76,14 @@ def _worker(rank, world, port, mode, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["bands", "even-bands", "frames"])
+@pytest.mark.parametrize("mode", ["bands", "even-bands", "rows", "frames"])
 def test_two_ranks_reproduce_the_single_process_image(tmp_path, mode):
     out_path = str(tmp_path / "out.npy")
     mp.spawn(_worker, args=(2, _free_port(), mode, out_path), nprocs=2, join=True)
     got = np.load(out_path)
     from oracle import binding as orc
     scene, desc, cam = _scene_and_desc()
-    if mode in ("bands", "even-bands"):
+    if mode in ("bands", "even-bands", "rows"):
         want, _, _, _ = orc.render(desc, _rd(cam))
         assert np.array_equal(got, want)
     else:
@@ -92,6 +102,17 @@ def test_band_partition_covers_the_frame_once():
                 seen[y0:y0 + h] += 1
         assert (seen == 1).all()
     assert rdist.frames_for_rank(10, 4, 1) == [1, 5, 9]
+    # interleaved groups of rows: one strided tile per rank
+    for world in (1, 2, 3, 8):
+        for height, group in ((1080, 8), (70, 8), (5, 8), (33, 4)):
+            seen = np.zeros(height, int)
+            counts = []
+            for r in range(world):
+                y0, rows, stride = rdist.rank_rows(height, world, r, group)
+                counts.append(rows)
+                for k in range(rows):
+                    seen[y0 + (k // group) * stride + k % group] += 1
+            assert (seen == 1).all() and sum(counts) == height
     # equal-share bands: every rank owns the same number of bands and, within a row, of rows
     for world in (1, 2, 3, 4, 8):
         seen = np.zeros(1080, int)

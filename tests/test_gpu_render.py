@@ -315,6 +315,51 @@ def test_stored_samples_equal_accumulated_ones(gpu, monkeypatch, kind):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.parametrize("kind", ["path", "whitted_soft", "whitted_1spp"])
+def test_interleaved_row_tile_equals_the_rows_of_the_frame(gpu, monkeypatch, kind):
+    """tile_row_group / tile_row_stride: a tile made of every stride-th group of rows (one rank's
+    share of a frame, rendered by one call) holds exactly those rows of the full-frame image,
+    packed; whatever the group size, the chunking and the sample storage mode."""
+    if kind == "path":
+        scene, cam = scenes.lens_scene()
+        kw = dict(integrator=abi.INTEGRATOR_PATH, n=2, max_depth=6, bias=1e-4, passes=2)
+    else:
+        scene, cam = scenes.mesh_scene(slices=60, stacks=30, ggx=True, square_light=True)
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=1 if kind == "whitted_1spp" else 2, max_depth=3, bias=1e-2, light_n=2)
+    desc = scene.frame(0.2)
+    Wd, Ht = 150, 91
+    with gpu.DeviceScene(desc) as ds:
+        full, sf = ds.render(scenes.render_desc(Wd, Ht, camera=cam, **kw))
+        monkeypatch.setenv("RTX_TWO_LANE_MIN", "128")
+        monkeypatch.setenv("RTX_MAX_PATHS", "8192")
+        rays = 0
+        for group, world in ((8, 3), (5, 2), (1, 4)):
+            from raytracer_amd import dist as rdist
+            seen = np.zeros(Ht, int)
+            for rank in range(world):
+                y0, rows, stride = rdist.rank_rows(Ht, world, rank, group)
+                if rows == 0:
+                    continue
+                idx = np.array([y0 + (k // group) * stride + k % group for k in range(rows)])
+                seen[idx] += 1
+                for extra in (0, abi.FLAG_ACCUMULATE_SAMPLES | abi.FLAG_STORE_CAMERA_RAYS):
+                    rd = scenes.render_desc(Wd, Ht, camera=cam, tile=(0, y0, Wd, rows), row_group=group, row_stride=stride,
+                                            flags=extra, **kw)
+                    got, st = ds.render(rd)
+                    assert np.array_equal(got.view(np.uint32), full[idx].view(np.uint32)), (group, world, rank, extra)
+                if group == 8:
+                    rays += st.rays
+            assert (seen == 1).all()
+        assert rays == sf.rays          # the ranks' shares add up to the frame's rays
+        # a stride below the group, or rows past the frame, are refused
+        bad = scenes.render_desc(Wd, Ht, camera=cam, tile=(0, 0, Wd, 16), row_group=8, row_stride=4, **kw)
+        with pytest.raises(RuntimeError):
+            ds.render(bad)
+        bad = scenes.render_desc(Wd, Ht, camera=cam, tile=(0, 80, Wd, 16), row_group=8, row_stride=16, **kw)
+        with pytest.raises(RuntimeError):
+            ds.render(bad)
+
+
 def test_overwrite_flag_equals_cleared_buffer(gpu):
     """RTX_FLAG_OVERWRITE: the first pass stores, later passes add; a buffer full of other
     values gives the image a cleared buffer gives."""

@@ -36,3 +36,21 @@ for world in (1, 2, 4, 8):
         for h in handles:
             h.close()
         print(f"world {world} bands/rank {bpr} streams {B}: slowest rank {worst:.3f} ms per frame", flush=True)
+    # the same share as ONE tile of interleaved groups of 8 rows, rendered by one call (two chunks on two streams)
+    for flags, tag in ((0, "two lanes"), (abi.FLAG_SERIAL_CHUNKS, "one stream")):
+        worst = 0.0
+        for rank in range(world):
+            y0, rows, stride = rdist.rank_rows(H, world, rank, 8)
+            buf = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
+            def frame(f):
+                rd = scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=scenes.orbit_camera(f / 30.0), n=4, light_n=2,
+                                        max_depth=3, bias=1e-2, frame=f, tile=(0, y0, W, rows), row_group=8, row_stride=stride, flags=flags)
+                ds.render_device(rd, buf.data_ptr())
+            frame(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for f in range(1, 6):
+                frame(f)
+            torch.cuda.synchronize()
+            worst = max(worst, (time.perf_counter() - t0) / 5 * 1e3)
+        print(f"world {world} one tile of interleaved 8-row groups, {tag}: slowest rank {worst:.3f} ms per frame", flush=True)
