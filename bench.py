@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--accumulate-samples", action="store_true",
                     help="clear the sample slots, add every term and resolve (RTX_FLAG_ACCUMULATE_SAMPLES) instead of "
                          "storing finished samples; same image, for comparison")
+    ap.add_argument("--store-light-rays", action="store_true",
+                    help="store every light ray's direction and light distance (RTX_FLAG_STORE_LIGHT_RAYS) instead of "
+                         "recomputing them from the origin; same image, for comparison")
     ap.add_argument("--no-serial-leg", action="store_true",
                     help="skip the untimed repeat of the frames with chunks one after the other (roofline.serial)")
     ap.add_argument("--walk", choices=["bvh", "kd-culled", "reference"], default="bvh",
@@ -110,6 +113,8 @@ def main():
         kflags |= abi.FLAG_STORE_CAMERA_RAYS
     if args.accumulate_samples:
         kflags |= abi.FLAG_ACCUMULATE_SAMPLES
+    if args.store_light_rays:
+        kflags |= abi.FLAG_STORE_LIGHT_RAYS
     stream = torch.cuda.current_stream().cuda_stream
     ds = device.DeviceScene(desc, stream=stream)
     # handle k renders the frames with step % F == k on stream k

@@ -228,13 +228,20 @@ enum {
                                            (same arithmetic, same image; 84 bytes per ray less
                                            to write and to read three times).  Implied by
                                            RTX_FLAG_REFILL_LANES                              */
-    RTX_FLAG_ACCUMULATE_SAMPLES = 1u << 16 /* every term of a sub-sample is added to a cleared
+    RTX_FLAG_ACCUMULATE_SAMPLES = 1u << 16,/* every term of a sub-sample is added to a cleared
                                            accumulator slot and a resolve launch sums the slots
                                            of a pixel.  Without it a slot whose whole value comes
                                            from one thread (pathTrace: always; rayTrace: when no
                                            material refracts) is stored once, and with one
                                            sub-sample per pixel written to the framebuffer at
                                            once.  Same image                                  */
+    RTX_FLAG_STORE_LIGHT_RAYS = 1u << 17  /* the first shading half stores every light ray's
+                                           direction and light distance in the shadow queue.
+                                           Without it, in a scene with one Point or Directional
+                                           light (no random numbers: the ray is a function of its
+                                           origin), only origins are stored and the traversal and
+                                           the second shading half recompute the rest.  Same
+                                           image                                               */
 };
 
 /* The reference's compile-time configuration (Raytracer.cpp:9-19,27-40;

@@ -42,6 +42,7 @@ FLAG_SERIAL_CHUNKS = 1 << 13
 FLAG_OVERWRITE = 1 << 14
 FLAG_STORE_CAMERA_RAYS = 1 << 15
 FLAG_ACCUMULATE_SAMPLES = 1 << 16
+FLAG_STORE_LIGHT_RAYS = 1 << 17
 
 TONEMAP_NONE, TONEMAP_CBRT = 0, 1
 

@@ -209,6 +209,7 @@ struct rtx_scene {
     uint32_t kd_depth = 0;
     uint32_t bvh_depth = 0;
     const float* srgb_thresholds = nullptr;     // device copy of srgb_thresholds(), for k_present
+    bool light_rays_plain = false;  // one light, Point or Directional, one sample per hit
     bool may_refract = false;       // some material can have transparency != 0 (rayTrace spawns a child then)
     std::vector<uint8_t> light_multisample;     // Light::multisample per light, kept on the host
     int compute_units = 0;
@@ -485,6 +486,8 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     for (uint32_t i = 0; i < s->n_materials; ++i)
         if (s->materials[i].transparency != 0.0 || s->materials[i].transparency_fn.kind != RTX_SAMPLER_CONST) sc->may_refract = true;
     for (uint32_t i = 0; i < s->n_lights; ++i) sc->light_multisample.push_back(s->lights[i].multisample ? 1 : 0);
+    sc->light_rays_plain = s->n_lights == 1 && !s->lights[0].multisample &&
+                           (s->lights[0].kind == RTX_LIGHT_POINT || s->lights[0].kind == RTX_LIGHT_DIRECTIONAL);
     lap("copy branches, boxes");
     BvhBuild bvh;
     std::vector<BvhPrim> bvh_prims;
@@ -702,6 +705,7 @@ int rtx_scene_clone(const rtx_scene* sc, rtx_scene** out)
     c->kd_depth = sc->kd_depth;
     c->bvh_depth = sc->bvh_depth;
     c->may_refract = sc->may_refract;
+    c->light_rays_plain = sc->light_rays_plain;
     c->srgb_thresholds = sc->srgb_thresholds;
     c->light_multisample = sc->light_multisample;
     c->compute_units = sc->compute_units;
@@ -805,7 +809,7 @@ static void hand_out_stats(rtx_scene* sc, rtx_stats* out)
 static int launch_trace(rtx_scene* sc, Workspace& ws, hipStream_t stream, const double* ox, const double* oy, const double* oz,
                         const double* dx, const double* dy, const double* dz, const double* limit, uint32_t n,
                         const uint32_t* n_device, uint32_t seg, uint32_t flags, int32_t* hit_prim, double* hit_depth, bool count,
-                        const CameraQueue* camera = nullptr)
+                        const CameraQueue* camera = nullptr, bool light_rays_from_origin = false)
 {
     CameraQueue cam;
     if (camera) cam = *camera; else std::memset(&cam, 0, sizeof cam);
@@ -845,7 +849,7 @@ static int launch_trace(rtx_scene* sc, Workspace& ws, hipStream_t stream, const 
     }
 #define RTX_LAUNCH_TRACE(COUNT, MODE)                                                                                  \
     hipLaunchKernelGGL((k_trace_pool<COUNT, MODE>), grid, block, 0, stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
-                       n_device, seg, linear, hit_prim, hit_depth, g, cam)
+                       n_device, seg, linear, hit_prim, hit_depth, g, cam, light_rays_from_origin ? 1u : 0u)
 #define RTX_LAUNCH_MODES(COUNT)                                                                   \
     switch (mode) {                                                                               \
     case 0: RTX_LAUNCH_TRACE(COUNT, 0); break;                                                    \
@@ -984,6 +988,10 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     // the level's traversal launch, the first of a chunk, clears the chunk's state.  The refilled
     // walk's kernels read rays from memory only.
     const bool camera_queue = !(rd->flags & (RTX_FLAG_STORE_CAMERA_RAYS | RTX_FLAG_REFILL_LANES));
+    // One light that takes no random numbers: its ray is a function of the origin alone, so the
+    // shadow queue carries origins only (40 bytes per light ray less to write and to read twice).
+    const bool light_rays_from_origin = whitted && sc->d.n_lights == 1 && sc->light_rays_plain &&
+                                        !(rd->flags & (RTX_FLAG_STORE_LIGHT_RAYS | RTX_FLAG_REFILL_LANES));
     // Sample slots that get their whole value from one thread of one launch are stored instead of
     // cleared, added to and read back: always so for pathTrace (weight x terminal radiance, added
     // once per path), for rayTrace when it spawns no children.  With one sub-sample per pixel the
@@ -1016,6 +1024,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         L.timer_p->stream = L.trace_timer_p->stream = L.st;
         L.p = p;
         L.p.direct_store = direct_store;
+        L.p.light_rays_from_origin = light_rays_from_origin ? 1u : 0u;
         L.p.accum = accum;
         L.p.queue_cap = (uint32_t)std::min<size_t>(L.w->capacity, 0xffffffffu);
         if (n_lanes > 1) HIP_TRY(hipStreamWaitEvent(L.st, sc->fork_event, 0));
@@ -1090,7 +1099,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
             if (shadow_max > 0) {
                 L.trace_timer_p->begin();
                 r = launch_trace(sc, w, st, w.sq.ox, w.sq.oy, w.sq.oz, w.sq.dx, w.sq.dy, w.sq.dz, w.sq.limit, (uint32_t)shadow_max,
-                                 hits, bound, rd->flags, nullptr, w.sq.hit_depth, count_work);
+                                 hits, bound, rd->flags, nullptr, w.sq.hit_depth, count_work, nullptr, light_rays_from_origin);
                 if (r != RTX_OK) return r;
                 L.trace_timer_p->end(&local.ms_shadow);
                 local.traverse_launches++;

@@ -80,6 +80,9 @@ struct RenderParams {
                                 //   nor read back.  2: as 1 with one sub-sample per pixel: the value goes
                                 //   straight into the framebuffer and no resolve launch follows
     float* accum;               // the framebuffer (direct_store == 2)
+    uint32_t light_rays_from_origin;    // 1: the scene's one light takes no random numbers (Point / Directional), so a
+                                //   light ray is a function of its origin: the shadow queue holds origins only and
+                                //   the traversal and the second shading half recompute direction and light distance
 };
 
 // What the traversal launch of such a level needs to make its own rays and to clear the
@@ -804,7 +807,7 @@ __global__ void __launch_bounds__(kTraceBlock)
 k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
              const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
              const double* __restrict__ limit, uint32_t n, const uint32_t* __restrict__ n_device, uint32_t seg,
-             uint32_t linear, int32_t* hit_prim, double* hit_depth, Counters g, CameraQueue cam)
+             uint32_t linear, int32_t* hit_prim, double* hit_depth, Counters g, CameraQueue cam, uint32_t light_rays_from_origin)
 {
     __shared__ int32_t stack[kStack * kTraceBlock];
     const uint32_t ray = blockIdx.x * kTraceBlock + threadIdx.x;
@@ -814,6 +817,7 @@ k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__
     uint32_t i, at;
     if (!ray_place(ray, n, n_device, seg, i, at)) return;
     d3 o, d;
+    double lim = kInf;          // any-hit walks: the light distance
     if (cam.on) {
         // level 0 of a chunk: ray i is the camera ray of sample slot i.  This launch is also the
         // first of the chunk, so it clears the chunk's state: the slot's accumulator and the
@@ -825,17 +829,24 @@ k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__
         }
         const Ray r = camera_ray(cam.p, i);
         o = r.o; d = r.d;
+    } else if (light_rays_from_origin) {
+        // Light::getRay / getDistance (PointLight.cpp:15-27, DirectionalLight.cpp:4-31) of the one light
+        o = mk(ox[at], oy[at], oz[at]);
+        const Ray lr = light_ray(s.lights[0], o, 0.0, 0.0);
+        d = lr.d;
+        lim = light_distance(s.lights[0], lr);
     } else {
         o = mk(ox[at], oy[at], oz[at]); d = mk(dx[i], dy[i], dz[i]);
+        if (MODE == 2 || MODE == 4) lim = limit[i];
     }
     Work<COUNT> w;
     int32_t bp = -1; double bd = kInf;
     bool settled = false;
     if (MODE != 0 && linear == 0 && culling_is_exact(o, d)) {
         if (MODE == 1) { trace_lane_culled<COUNT, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w); settled = true; }
-        else if (MODE == 2) { trace_lane_culled<COUNT, true>(s, o, d, limit[i], stack + threadIdx.x, bp, bd, w); settled = true; }
+        else if (MODE == 2) { trace_lane_culled<COUNT, true>(s, o, d, lim, stack + threadIdx.x, bp, bd, w); settled = true; }
         else if (MODE == 3) settled = trace_lane_bvh<COUNT, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w);
-        else settled = trace_lane_bvh<COUNT, true>(s, o, d, limit[i], stack + threadIdx.x, bp, bd, w);
+        else settled = trace_lane_bvh<COUNT, true>(s, o, d, lim, stack + threadIdx.x, bp, bd, w);
     }
     if (!settled) {
         if constexpr (COUNT) w.fallback++;
@@ -1386,6 +1397,7 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
             for (uint32_t sm = 0; sm < samples; ++sm, k += p.seg) {
                 double u0 = 0.0, u1 = 0.0;
                 if (l.kind == RTX_LIGHT_SQUARE) { u0 = rng_next(rng); u1 = rng_next(rng); }
+                if (p.light_rays_from_origin) continue;     // recomputed from the origin where it is needed
                 Ray lr = light_ray(l, from, u0, u1);
                 sq.dx[k] = lr.d.x; sq.dy[k] = lr.d.y; sq.dz[k] = lr.d.z;
                 sq.limit[k] = light_distance(l, lr);
@@ -1445,9 +1457,17 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
                 uint32_t samples = l.multisample ? p.d.light_multisample_n * p.d.light_multisample_n : 1u;
                 for (uint32_t sm = 0; sm < samples; ++sm, k += stride) {
                     // light->getDistance(lightRay) (:490) was evaluated when the ray was made
-                    const double ldist = sq.limit[k];
+                    double ldist;
+                    d3 ld;
+                    if (p.light_rays_from_origin) {
+                        const Ray lr = light_ray(l, h.position + (h.normal * p.d.bias), 0.0, 0.0);
+                        ld = lr.d;
+                        ldist = light_distance(l, lr);
+                    } else {
+                        ldist = sq.limit[k];
+                    }
                     if (ldist < sq.hit_depth[k]) {
-                        const d3 ld = mk(sq.dx[k], sq.dy[k], sq.dz[k]);
+                        if (!p.light_rays_from_origin) ld = mk(sq.dx[k], sq.dy[k], sq.dz[k]);
                         double att = light_attenuation(l, ldist, p.d.attenuation);
                         direct = direct + lighting(s, inv_dir, ld, h.normal, h.u, h.v, att, m, ld3(l.color));
                     }

@@ -360,6 +360,35 @@ def test_interleaved_row_tile_equals_the_rows_of_the_frame(gpu, monkeypatch, kin
             ds.render(bad)
 
 
+@pytest.mark.parametrize("kind", ["point_refract", "directional_mesh", "walks"])
+def test_light_rays_recomputed_from_their_origin_equal_stored_ones(gpu, monkeypatch, kind):
+    """One Point or Directional light: a light ray is a function of its origin, so by default the
+    shadow queue holds origins only and the traversal and the second shading half recompute
+    direction and light distance; RTX_FLAG_STORE_LIGHT_RAYS stores them.  Same bits, same work."""
+    if kind == "point_refract":
+        scene, cam = scenes.whitted_scene()
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=2, max_depth=5)
+    else:
+        scene, cam = scenes.mesh_scene(slices=60, stacks=30)
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=1, max_depth=2, bias=1e-2)
+    desc = scene.frame(0.2)
+    monkeypatch.setenv("RTX_TWO_LANE_MIN", "128")
+    monkeypatch.setenv("RTX_MAX_PATHS", "8192")
+    walks = (0, abi.FLAG_KD_CULLED, abi.FLAG_REFERENCE_ORDER) if kind == "walks" else (0,)
+    with gpu.DeviceScene(desc) as ds:
+        for walk in walks:
+            f = walk | abi.FLAG_COUNTERS
+            a, sa = ds.render(scenes.render_desc(150, 90, camera=cam, flags=f, **kw))
+            b, sb = ds.render(scenes.render_desc(150, 90, camera=cam, flags=f | abi.FLAG_STORE_LIGHT_RAYS, **kw))
+            _same_ray_counts(sa, sb)
+            assert sa.rays_shadow > 0
+            for k in ("content_tests", "triangle_tests", "sphere_tests", "aabb_tests", "hits_accepted", "fallback_rays",
+                      "branch_visits", "leaf_visits"):
+                assert getattr(sa, k) == getattr(sb, k), k
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            assert np.isfinite(a).all() and a.max() > 0
+
+
 def test_overwrite_flag_equals_cleared_buffer(gpu):
     """RTX_FLAG_OVERWRITE: the first pass stores, later passes add; a buffer full of other
     values gives the image a cleared buffer gives."""
