@@ -729,6 +729,7 @@ int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* directi
     const double *d_o = nullptr, *d_d = nullptr;
     HIP_TRY(tmp.upload(origin, n * 3, &d_o));
     HIP_TRY(tmp.upload(direction, n * 3, &d_d));
+    HIP_TRY(tmp.finish());          // the copies run on a stream of their own: the kernel below must not overtake them
     auto dalloc = [&](size_t bytes, void** p) -> hipError_t {
         hipError_t e = hipMalloc(p, bytes);
         if (e == hipSuccess) tmp.ptrs.push_back(*p);
