@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -30,6 +31,10 @@ using namespace rtx;
 namespace {
 
 thread_local std::string g_error;
+// The device rtx_init chose.  HIP's current device is a per-thread setting that starts at 0 on
+// every new thread, so each entry point selects its device itself: rtx_scene_create this one,
+// everything that takes a scene the scene's.  -1 (no rtx_init yet): the calling thread's current.
+std::atomic<int> g_device{-1};
 
 int fail(int code, const char* fmt, ...)
 {
@@ -46,6 +51,11 @@ int fail(int code, const char* fmt, ...)
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
         if (e_ != hipSuccess) return fail(RTX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define USE_DEVICE(dev)                                                                       \
+    do {                                                                                      \
+        if ((dev) >= 0) HIP_TRY(hipSetDevice(dev));                                           \
     } while (0)
 
 struct DeviceBuffers {
@@ -252,6 +262,7 @@ int ensure_workspace(Workspace& w, size_t cap, size_t shadow_cap, size_t gather_
 {
     if (!w.counts) {
         HIP_TRY(hipMalloc(&w.counts, 8 * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(w.counts, 0, 8 * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&w.work, 16 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(w.work, 0, 16 * sizeof(unsigned long long)));     // zero between collections
         HIP_TRY(hipMalloc(&w.bins, 2 * kBins * sizeof(uint32_t)));
@@ -351,6 +362,20 @@ int validate_scene(const rtx_scene_desc* s, uint32_t* kd_depth)
         if (s->prim_type[i] != RTX_PRIM_BICONVEX && s->prim_material[i] >= s->n_materials)
             return fail(RTX_ERR_INVALID, "prim %u: material out of range", i);
     }
+    // the host-side builders sort on these: a NaN breaks their comparators' ordering
+    for (uint32_t i = 0; i < s->n_prims; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const double lo = s->prim_aabb_min[3 * (size_t)i + k], hi = s->prim_aabb_max[3 * (size_t)i + k];
+            if (!std::isfinite(lo) || !std::isfinite(hi) || lo > hi)
+                return fail(RTX_ERR_INVALID, "prim %u: bounding box is not finite or is inverted", i);
+        }
+    for (uint32_t i = 0; i < s->n_branches; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const double lo = s->branch_min[3 * (size_t)i + k], hi = s->branch_max[3 * (size_t)i + k];
+            // (a child region clipped at a split plane outside its parent's box is inverted: legal)
+            if (std::isnan(lo) || std::isnan(hi) || std::isnan(s->branch_value[i]))
+                return fail(RTX_ERR_INVALID, "KD branch %u: box or split value is NaN", i);
+        }
     for (uint32_t i = 0; i < 2 * s->n_lenses; ++i) {
         uint32_t p = s->lens_spheres[i];
         if (p >= s->n_prims || s->prim_type[p] != RTX_PRIM_SPHERE) return fail(RTX_ERR_INVALID, "lens %u: inner sphere id invalid", i / 2);
@@ -421,6 +446,7 @@ int rtx_init(int device)
     HIP_TRY(hipGetDeviceProperties(&prop, cur));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RTX_ERR_NO_GPU, "device %d is %s; this library is built for gfx950 only", cur, prop.gcnArchName);
+    g_device.store(cur);
     return RTX_OK;
 }
 
@@ -432,6 +458,7 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     int rc = validate_scene(s, &kd_depth);
     if (rc != RTX_OK) return rc;
     if (rtx_device_count() <= 0) return fail(RTX_ERR_NO_GPU, "no HIP device is visible");
+    USE_DEVICE(g_device.load());        // a worker thread that prepares the next frame starts on device 0
 
     // RTX_TIMINGS=1: the host stages of this call, in milliseconds, on stderr
     const bool timings = std::getenv("RTX_TIMINGS") != nullptr;
@@ -698,6 +725,7 @@ int rtx_scene_set_stream(rtx_scene* sc, void* hip_stream)
 int rtx_scene_clone(const rtx_scene* sc, rtx_scene** out)
 {
     if (!sc || !out) return fail(RTX_ERR_INVALID, "null argument");
+    USE_DEVICE(sc->device);
     rtx_scene* c = new rtx_scene();
     c->d = sc->d;
     c->buffers = sc->buffers;
@@ -715,7 +743,11 @@ int rtx_scene_clone(const rtx_scene* sc, rtx_scene** out)
     return RTX_OK;
 }
 
-void rtx_scene_destroy(rtx_scene* sc) { delete sc; }
+void rtx_scene_destroy(rtx_scene* sc)
+{
+    if (sc) (void)hipSetDevice(sc->device);     // its streams and buffers are released on their own device
+    delete sc;
+}
 
 int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* direction, size_t n, uint32_t flags,
                       int32_t* prim, double* depth, double* position, double* normal, double* uv, double* bary,
@@ -725,6 +757,7 @@ int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* directi
     if (!sc || !origin || !direction || !prim || !depth) return fail(RTX_ERR_INVALID, "null argument");
     if (n == 0) return RTX_OK;
     if (n > 0x7fffffffu) return fail(RTX_ERR_LIMIT, "at most 2^31-1 rays per call");
+    USE_DEVICE(sc->device);
     DeviceBuffers tmp;
     const double *d_o = nullptr, *d_d = nullptr;
     HIP_TRY(tmp.upload(origin, n * 3, &d_o));
@@ -870,6 +903,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
 {
     if (!sc || !rd || !accum) return fail(RTX_ERR_INVALID, "null argument");
     if (rd->integrator > RTX_INTEGRATOR_WHITTED) return fail(RTX_ERR_INVALID, "unknown integrator");
+    USE_DEVICE(sc->device);
     if (rd->width < 2 || rd->height < 2) return fail(RTX_ERR_INVALID, "frame must be at least 2x2");
     if (rd->tile_w == 0 || rd->tile_h == 0 || rd->tile_x0 + (uint64_t)rd->tile_w > rd->width)
         return fail(RTX_ERR_INVALID, "tile outside the frame");
@@ -1027,7 +1061,9 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         L.p.direct_store = direct_store;
         L.p.light_rays_from_origin = light_rays_from_origin ? 1u : 0u;
         L.p.accum = accum;
-        L.p.queue_cap = (uint32_t)std::min<size_t>(L.w->capacity, 0xffffffffu);
+        // this call's own capacity, the one the host checks lengths against below -- not the
+        // workspace's, which an earlier, larger call may have grown
+        L.p.queue_cap = (uint32_t)std::min<size_t>(queue_cap, 0xffffffffu);
         if (n_lanes > 1) HIP_TRY(hipStreamWaitEvent(L.st, sc->fork_event, 0));
     }
 
@@ -1237,6 +1273,7 @@ int rtx_scene_set_async(rtx_scene* sc, int enabled)
 int rtx_scene_wait(rtx_scene* sc, rtx_stats* totals)
 {
     if (!sc) return fail(RTX_ERR_INVALID, "null scene");
+    USE_DEVICE(sc->device);
     for (int k = 0; k < 2; ++k)
         if (sc->ws[k].work) HIP_TRY(enqueue_work_readback(sc->ws[k], sc->stream));    // the lanes have been joined to it
     HIP_TRY(hipStreamSynchronize(sc->stream));
@@ -1248,6 +1285,7 @@ int rtx_render(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rtx_stats
 {
     if (!sc || !rd || !accum) return fail(RTX_ERR_INVALID, "null argument");
     if (sc->async) return fail(RTX_ERR_INVALID, "asynchronous scene: use rtx_render_device");
+    USE_DEVICE(sc->device);
     size_t bytes = (size_t)rd->tile_w * rd->tile_h * 3 * sizeof(float);
     if (bytes == 0) return fail(RTX_ERR_INVALID, "empty tile");
     float* d_accum = nullptr;
@@ -1271,6 +1309,7 @@ int rtx_present_device(rtx_scene* sc, const float* accum, uint32_t width, uint32
     if (width == 0 || height == 0 || (uint64_t)width * height * 3 > 0xffffffffull) return fail(RTX_ERR_INVALID, "bad frame size");
     if (passes == 0 || tonemap > RTX_TONEMAP_CBRT) return fail(RTX_ERR_INVALID, "bad passes / tonemap");
     if (height > 65535u) return fail(RTX_ERR_LIMIT, "more than 65535 rows");
+    USE_DEVICE(sc->device);
     hipLaunchKernelGGL(k_present, dim3(grid_for((size_t)width * 3).x, height), dim3(kBlock), 0, sc->stream, accum, width, height,
                        (float)passes, tonemap, flip ? 1u : 0u, sc->srgb_thresholds, rgb8);
     HIP_TRY(hipGetLastError());
@@ -1283,6 +1322,7 @@ int rtx_present(rtx_scene* sc, const float* accum, uint32_t width, uint32_t heig
 {
     if (!sc || !accum || !rgb8) return fail(RTX_ERR_INVALID, "null argument");
     if (sc->async) return fail(RTX_ERR_INVALID, "asynchronous scene: use rtx_present_device");
+    USE_DEVICE(sc->device);
     size_t total = (size_t)width * height * 3;
     if (total == 0) return fail(RTX_ERR_INVALID, "bad frame size");
     float* d_accum = nullptr;

@@ -811,6 +811,9 @@ k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__
 {
     __shared__ int32_t stack[kStack * kTraceBlock];
     const uint32_t ray = blockIdx.x * kTraceBlock + threadIdx.x;
+    // Level 0 of a chunk is the chunk's first launch and clears the ring of queue lengths: before
+    // any thread leaves, since a chunk may hold fewer rays than the ring has words.
+    if (cam.on && ray < 8u) cam.counts[ray] = 0u;
     // the grid is sized for n; when the real queue length is only known on the device
     // (n_device), the surplus workgroups leave here
     if (ray >= ray_total(n, n_device, seg)) return;
@@ -819,10 +822,8 @@ k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__
     d3 o, d;
     double lim = kInf;          // any-hit walks: the light distance
     if (cam.on) {
-        // level 0 of a chunk: ray i is the camera ray of sample slot i.  This launch is also the
-        // first of the chunk, so it clears the chunk's state: the slot's accumulator and the
-        // ring of queue lengths.
-        if (ray < 8u) cam.counts[ray] = 0u;
+        // ray i is the camera ray of sample slot i; the slot's accumulator is part of the chunk's
+        // state and cleared here as well
         if (cam.clear_samples) {
             double* acc = cam.sample + 3 * (size_t)i;
             acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0;

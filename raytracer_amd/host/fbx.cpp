@@ -69,9 +69,13 @@ struct Reader {
     std::vector<uint8_t> arrayBytes(size_t& pos, size_t count, size_t elem) const {
         uint32_t encoding = get<uint32_t>(pos), clen = get<uint32_t>(pos);
         if (pos + clen > size) throw std::runtime_error("FBX: truncated array");
-        std::vector<uint8_t> out(count * elem);
+        // the element count comes from the file: it is checked against the bytes that are really
+        // there before anything of that size is allocated (deflate expands at most 1032-fold)
+        const uint64_t want = (uint64_t)count * elem;
+        if (encoding == 0 ? want != clen : want > (uint64_t)clen * 1032u + 64u)
+            throw std::runtime_error("FBX: array length mismatch");
+        std::vector<uint8_t> out(want);
         if (encoding == 0) {
-            if (clen != out.size()) throw std::runtime_error("FBX: array length mismatch");
             std::memcpy(out.data(), b + pos, clen);
         } else {
             uLongf n = (uLongf)out.size();
@@ -135,6 +139,7 @@ struct Reader {
         bool keep = depth == 0 ? (out.name == "Objects" || out.name == "Connections") : false;
         for (const char* k : kept) if (depth > 0 && out.name == k) keep = true;
         if (!keep) { pos = end; return true; }
+        if (nprops > plen) throw std::runtime_error("FBX: bad property count");     // a property takes at least a byte
         out.props.reserve(nprops);
         for (uint64_t k = 0; k < nprops; ++k) out.props.push_back(prop(pos));
         while (pos < end) {

@@ -7,6 +7,8 @@ the pieces its three main() variants show (Raytracer-Noah-Desktop.cpp:665-754,
 Raytracer-noah-laptop.cpp:584-611) with seeded procedural geometry standing in
 for the FBX meshes (which need the absent assimp to import).
 """
+import os
+
 import numpy as np
 
 from . import abi
@@ -144,12 +146,29 @@ def checker_texture(size=256, cells=8, seed=7):
     return np.clip(base + noise, 0, 255).astype(np.uint8)
 
 
-def mesh_scene(slices=246, stacks=123, t=0.0, ggx=False, square_light=False):
+_GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def reference_mesh(name):
+    """Triangle soup of one of the reference's FBX models (Raytracer/Models/<name>/<name>.fbx as
+    addModel places it, Raytracer.cpp:362-366), from the fixture tools/make_mesh_fixture.py
+    wrote: per-corner position [n,9], normal [n,9], uv [n,6], bit for bit what the FBX reader
+    hands to the Triangle constructor.  'backpack' (67 908 triangles) is the model the
+    reference's mesh scene loads (Raytracer-noah-laptop.cpp:597); 'teapot' has 15 704."""
+    z = np.load(os.path.join(_GOLDEN, f"mesh_{name}.npz"))
+    c = z["records"][z["index"]]                # [n, 3, 8]
+    n = len(c)
+    return (np.ascontiguousarray(c[:, :, 0:3]).reshape(n, 9), np.ascontiguousarray(c[:, :, 3:6]).reshape(n, 9),
+            np.ascontiguousarray(c[:, :, 6:8]).reshape(n, 6))
+
+
+def mesh_scene(slices=246, stacks=123, t=0.0, ggx=False, square_light=False, mesh=None):
     """Configs 2 and 4: a triangle mesh + floor.  Config 2: constant white material,
     DirectionalLight((-1,-1,-1)) (Raytracer-noah-laptop.cpp:608-611), orbit camera
     eye = (10 sin t, 0.1, 10 cos t) (:672).  Config 4 (ggx=True): smoothness/metalness
     > 0, albedo texture on the mesh, checker floor and (square_light) a 1x1 SquareLight
-    at (0,10,0) facing down (Raytracer-Noah-Desktop.cpp:754)."""
+    at (0,10,0) facing down (Raytracer-Noah-Desktop.cpp:754).  `mesh` names a reference
+    model (reference_mesh) instead of the seeded procedural soup."""
     s = HostScene()
     if ggx:
         tex = s.texture(checker_texture())
@@ -159,7 +178,7 @@ def mesh_scene(slices=246, stacks=123, t=0.0, ggx=False, square_light=False):
     else:
         mesh_mat = s.material("PlainWhiteTees")
         floor_mat = s.material("PlainWhiteTees", color=(0.8, 0.8, 0.8))
-    pos, nrm, uv = bumpy_sphere(slices, stacks)
+    pos, nrm, uv = reference_mesh(mesh) if mesh else bumpy_sphere(slices, stacks)
     s.triangles(pos, nrm, uv, mesh_mat)
     _floor(s, floor_mat, half=20.0, y=-3.0)
     if square_light:
