@@ -227,5 +227,35 @@ def animated_scene(copies=1, slices=246, stacks=123):
     return s
 
 
+def scalar_sampler_scene():
+    """Every scalar material channel driven by a sampler (Material.cpp:111-161): ns, ni,
+    transparency, metalness and smoothness come from doubleCheckers10x10 (Procedural.cpp:16-25)
+    or from Texture::doubleSample (Texture.cpp:56-64) somewhere in the scene, under a point light
+    (rayTrace) and an emissive sphere (pathTrace).  Texture values stay inside (0.2, 0.9) so that
+    sampled indices of refraction and exponents are ordinary numbers."""
+    s = HostScene()
+    rng = np.random.default_rng(21)
+    grey = rng.integers(60, 230, size=(32, 48, 3)).astype(np.uint8)
+    tex = s.texture(grey)
+    ck, td = abi.SAMPLER_DOUBLE_CHECKERS, abi.SAMPLER_TEXTURE_DOUBLE
+    floor = s.material_custom((1.0, 1.0, 1.0), ns=20.0, ni=1.0, transparency=0.0, metalness=0.3, smoothness=0.5,
+                              samplers={"color": (abi.SAMPLER_RY_CHECKERS, 0), "smoothness": (ck, 0), "metalness": (td, tex)})
+    _floor(s, floor, half=12.0)
+    glassy = s.material_custom((0.9, 0.95, 1.0), ns=30.0, ni=1.5, transparency=0.5, metalness=0.1, smoothness=0.6,
+                               samplers={"transparency": (td, tex), "ns": (ck, 0)})
+    s.sphere((-2.2, 2.0, 0.0), 2.0, glassy)
+    patchy = s.material_custom((1.0, 0.8, 0.6), ns=10.0, ni=1.3, transparency=0.0, metalness=0.5, smoothness=0.5,
+                               samplers={"transparency": (ck, 0), "ni": (td, tex), "ns": (td, tex)})
+    s.sphere((2.4, 1.6, -1.5), 1.6, patchy)
+    pos, nrm, uv = bumpy_sphere(40, 20, radius=1.2, center=(0.3, 1.2, 2.8))
+    mesh = s.material_custom((0.7, 0.9, 0.7), ns=50.0, ni=1.0, transparency=0.0, metalness=0.5, smoothness=0.5,
+                             samplers={"smoothness": (td, tex), "metalness": (ck, 0)})
+    s.triangles(pos, nrm, uv, mesh)
+    s.sphere((0.0, 14.0, 3.0), 4.0, s.material("PlainWhiteTees", emission=(5.0, 5.0, 5.0)))
+    s.point_light((5.0, 6.0, 6.0), (1.0, 1.0, 1.0))
+    cam = make_camera((0.0, 3.5, 9.5), (0.0, 1.2, 0.0))
+    return s, cam
+
+
 def orbit_camera(t, radius=10.0, height=0.1):
     return make_camera((radius * np.sin(t), height, radius * np.cos(t)), (0.0, 0.0, 0.0))

@@ -1,0 +1,245 @@
+"""GPU parity of the benchmark configurations and of the sampler channels the other render
+tests do not reach, against the CPU oracle (through the C ABI).
+
+Tolerances as in test_gpu_render.py: ray counts equal; RGB within 1e-4 relative for
+single-bounce images, >= 60 dB PSNR and 99.9 % of the values within 1e-4 for multi-bounce ones
+(device and host libm differ in the last bits of pow / acos / atan2, and a sphere's uv passes
+through atan2 before it indexes a checker or a texel)."""
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, scenes
+from oracle import binding as orc
+from helpers import psnr, rel_err
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+
+
+def _same_ray_counts(a, b):
+    assert (a.rays_primary, a.rays_secondary, a.rays_shadow) == (b.rays_primary, b.rays_secondary, b.rays_shadow)
+
+
+def _close(img, ref, multi_bounce):
+    assert np.isfinite(img).all()
+    if multi_bounce:
+        assert psnr(img, ref) >= 60.0
+        assert np.quantile(rel_err(img, ref), 0.999) < REL_TOL
+    else:
+        assert rel_err(img, ref).max() < REL_TOL
+
+
+def test_config1_whitted_scene_at_its_real_size(gpu):
+    """BASELINE configs[0] as stated: 640x480, 1 spp, one PointLight, depth 1, reference-order walk
+    with the reference's own work counters."""
+    scene, cam = scenes.whitted_scene()
+    desc = scene.frame(0.0)
+    rd = scenes.render_desc(640, 480, integrator=abi.INTEGRATOR_WHITTED, camera=cam, max_depth=1, bias=1e-3,
+                            flags=abi.FLAG_COUNTERS | abi.FLAG_REFERENCE_ORDER)
+    with gpu.DeviceScene(desc) as ds:
+        img, stats = ds.render(rd)
+        rd.flags = 0
+        fast, fstats = ds.render(rd)
+    ref, _, ref_stats, _ = orc.render(desc, rd)
+    _same_ray_counts(stats, ref_stats)
+    _same_ray_counts(fstats, ref_stats)
+    assert stats.rays_primary == 640 * 480 and stats.rays_shadow > 0 and stats.rays_secondary > 0
+    for k in ("branch_visits", "leaf_visits", "aabb_tests", "triangle_tests", "sphere_tests", "hits_accepted"):
+        assert getattr(stats, k) == getattr(ref_stats, k), k
+    _close(img, ref, multi_bounce=False)
+    assert np.array_equal(fast.view(np.uint32), img.view(np.uint32))
+
+
+@pytest.mark.parametrize("integrator", ["whitted", "path"])
+def test_scalar_samplers_double_checkers_and_texture_double(gpu, integrator):
+    """ns / ni / transparency / metalness / smoothness from doubleCheckers10x10 and
+    Texture::doubleSample (Procedural.cpp:16-25, Texture.cpp:56-64, Material.cpp:111-161)."""
+    scene, cam = scenes.scalar_sampler_scene()
+    desc = scene.frame(0.0)
+    kinds = set()
+    for m in range(desc.n_materials):
+        mat = desc.materials[m]
+        for f in (mat.ns_fn, mat.ni_fn, mat.transparency_fn, mat.metalness_fn, mat.smoothness_fn):
+            kinds.add(f.kind)
+    assert {abi.SAMPLER_DOUBLE_CHECKERS, abi.SAMPLER_TEXTURE_DOUBLE} <= kinds
+    if integrator == "whitted":
+        rd = scenes.render_desc(200, 150, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=1, max_depth=4, bias=1e-3,
+                                clear=(0.21, 0.78, 0.95))
+    else:
+        rd = scenes.render_desc(160, 120, integrator=abi.INTEGRATOR_PATH, camera=cam, n=2, max_depth=6, bias=1e-4,
+                                clear=(0.5, 0.6, 0.7), passes=2, seed=13)
+    with gpu.DeviceScene(desc) as ds:
+        img, stats = ds.render(rd)
+        # the samplers must matter: the same scene with the channels' constants instead differs
+    ref, _, ref_stats, _ = orc.render(desc, rd)
+    _same_ray_counts(stats, ref_stats)
+    assert stats.rays_secondary > 0
+    _close(img, ref, multi_bounce=True)
+    assert img.max() > 0.2
+
+
+def test_scalar_samplers_change_the_image(gpu):
+    """Guard against a sampler that silently falls back to the constant: switching the sampled
+    channels to their constants must change the picture."""
+    import ctypes as C
+    scene, cam = scenes.scalar_sampler_scene()
+    desc = scene.frame(0.0)
+    rd = scenes.render_desc(120, 90, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=1, max_depth=4, bias=1e-3)
+    with gpu.DeviceScene(desc) as ds:
+        sampled, _ = ds.render(rd)
+    mats = (abi.Material * desc.n_materials)()
+    C.memmove(mats, desc.materials, C.sizeof(mats))
+    for m in mats:
+        for name in ("ns_fn", "ni_fn", "transparency_fn", "metalness_fn", "smoothness_fn"):
+            getattr(m, name).kind = abi.SAMPLER_CONST
+    keep = desc.materials
+    desc.materials = C.cast(mats, C.POINTER(abi.Material))
+    try:
+        with gpu.DeviceScene(desc) as ds:
+            const, _ = ds.render(rd)
+        ref, _, _, _ = orc.render(desc, rd)
+    finally:
+        desc.materials = keep
+    assert rel_err(const, ref).max() < REL_TOL
+    assert np.abs(sampled - const).max() > 0.05
+
+
+@pytest.mark.parametrize("mesh,integrator", [("teapot", "whitted"), ("teapot", "path"), ("backpack", "whitted")])
+def test_reference_fbx_model_on_the_hot_path(gpu, mesh, integrator):
+    """A model from the reference's Models/ directory (read by host/fbx.cpp, stored as a fixture by
+    tools/make_mesh_fixture.py) through the reference's KD tree, hard shadows from the
+    DirectionalLight of the reference's mesh scene (Raytracer-noah-laptop.cpp:597-611), against the
+    oracle.  The teapot is about 150 units wide, the backpack about 5."""
+    scene, _ = scenes.mesh_scene(mesh=mesh, ggx=(integrator == "path"))
+    if integrator == "path":
+        scene.sphere((0.0, 300.0, 0.0), 120.0, scene.material("PlainWhiteTees", emission=(4.0, 4.0, 4.0)))
+    desc = scene.frame(0.0)
+    assert desc.n_triangles == {"teapot": 15704, "backpack": 67908}[mesh] + 2
+    cam = scenes.orbit_camera(0.7, radius=190.0, height=70.0) if mesh == "teapot" else scenes.orbit_camera(0.7)
+    if mesh == "teapot":
+        from raytracer_amd.host import make_camera
+        cam = make_camera((190.0 * np.sin(0.7), 110.0, 190.0 * np.cos(0.7)), (0.0, 35.0, 0.0))
+    if integrator == "whitted":
+        rd = scenes.render_desc(160, 90, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=1, max_depth=3, bias=1e-2,
+                                clear=(0.21, 0.78, 0.95), flags=abi.FLAG_COUNTERS)
+    else:
+        rd = scenes.render_desc(128, 72, integrator=abi.INTEGRATOR_PATH, camera=cam, n=2, max_depth=4, bias=1e-3,
+                                clear=(0.5, 0.5, 0.5), seed=5)
+    with gpu.DeviceScene(desc) as ds:
+        img, stats = ds.render(rd)
+        o, d = orc.camera_rays(rd)
+        got = ds.trace_closest(o, d, want_counters=True)
+    ref, _, ref_stats, _ = orc.render(desc, rd)
+    _same_ray_counts(stats, ref_stats)
+    want = orc.trace_closest(desc, o, d, want_counters=True)
+    assert np.array_equal(got["prim"], want["prim"]) and np.array_equal(got["depth"], want["depth"])
+    assert np.array_equal(got["leaf_hash"], want["leaf_hash"]) and np.array_equal(got["counters"], want["counters"])
+    hit_mesh = np.count_nonzero((want["prim"] >= 0) & (want["prim"] < desc.n_triangles - 2))
+    assert hit_mesh > 0.05 * len(o), "the model should fill a good part of the picture"
+    _close(img, ref, multi_bounce=(integrator == "path"))
+    if integrator == "whitted":
+        assert stats.rays_shadow > 0 and stats.fallback_rays <= stats.rays // 100
+
+
+def test_small_tiles_after_a_larger_render_on_the_same_handle(gpu):
+    """Chunks with fewer sample slots than the ring of queue lengths has words (a 2x2 frame, a
+    3x1 tile), rendered after a larger frame on the same handle, whose queue lengths are still in
+    the workspace: Whitted with a light, and path traced, against the oracle."""
+    scene, cam = scenes.whitted_scene()
+    desc = scene.frame(0.0)
+    with gpu.DeviceScene(desc) as ds:
+        for integrator, kw in ((abi.INTEGRATOR_WHITTED, dict(max_depth=3)),
+                               (abi.INTEGRATOR_PATH, dict(max_depth=4, bias=1e-4, seed=3, clear=(0.4, 0.4, 0.4)))):
+            big = scenes.render_desc(96, 64, integrator=integrator, camera=cam, **kw)
+            ds.render(big)
+            for W, H, tile in ((2, 2, None), (96, 64, (40, 30, 3, 1)), (96, 64, (17, 5, 1, 1)), (7, 3, None)):
+                for flags in (0, abi.FLAG_STORE_CAMERA_RAYS, abi.FLAG_ACCUMULATE_SAMPLES):
+                    rd = scenes.render_desc(W, H, integrator=integrator, camera=cam, tile=tile, flags=flags, **kw)
+                    img, stats = ds.render(rd)
+                    ref, _, ref_stats, _ = orc.render(desc, rd)
+                    _same_ray_counts(stats, ref_stats)
+                    assert np.isfinite(img).all()
+                    assert rel_err(img, ref).max() < REL_TOL, (integrator, W, H, tile, flags)
+                ds.render(big)
+
+
+def test_trace_right_after_create_on_a_non_default_stream(gpu):
+    """rtx_trace_closest uploads its rays on a copy stream of its own and launches on the scene's
+    stream; the launch must wait for the upload.  A large batch on a handle with a non-default
+    stream, straight after rtx_scene_create (whose own uploads are still fresh), against the oracle."""
+    import torch
+    scene, cam = scenes.live_scene()
+    desc = scene.frame(0.4)
+    rd = scenes.render_desc(1200, 900, integrator=abi.INTEGRATOR_PATH, camera=cam, n=1)
+    o, d = orc.camera_rays(rd)
+    want = orc.trace_closest(desc, o, d)
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        with gpu.DeviceScene(desc, stream=side.cuda_stream) as ds:
+            got = ds.trace_closest(o, d)
+        assert np.array_equal(got["prim"], want["prim"])
+        assert np.array_equal(got["depth"], want["depth"])
+        assert np.array_equal(got["leaf_hash"], want["leaf_hash"])
+
+
+def test_config5_animated_scene_reduced_against_the_oracle(gpu):
+    """BASELINE configs[4] at reduced size: bumpy-sphere copies + checker floor + three emissive
+    spheres on circle0/1/2 (Animatable.cpp:22-35), path traced, two frames of the sequence."""
+    s = scenes.animated_scene(copies=2, slices=48, stacks=24)
+    for frame, t in ((3, 3 / 30.0), (40, 40 / 30.0)):
+        desc = s.frame(t)
+        cam = scenes.orbit_camera(t, radius=30.0, height=6.0)
+        rd = scenes.render_desc(128, 72, integrator=abi.INTEGRATOR_PATH, camera=cam, n=2, max_depth=6, bias=1e-3,
+                                frame=frame, seed=1)
+        with gpu.DeviceScene(desc) as ds:
+            img, stats = ds.render(rd)
+        ref, _, ref_stats, _ = orc.render(desc, rd)
+        _same_ray_counts(stats, ref_stats)
+        assert stats.rays_secondary > 0
+        _close(img, ref, multi_bounce=True)
+        assert img.max() > 0.05
+
+
+def test_config5_full_size_frame_properties(gpu):
+    """BASELINE configs[4] at its full size: ~960 k triangles, three animated emissive spheres,
+    3840x2160 at 64 spp (n = 8), path depth 8 -- 530 M camera paths, hours for the CPU oracle.
+    Size-independent properties instead: a tile of the frame rendered on its own (with all three
+    walks, bit-identical) equals that region of the whole frame; ray counts add up; two frames of
+    the animation differ where the spheres moved; everything is finite."""
+    import torch
+    s = scenes.animated_scene(copies=16)
+    W, H = 3840, 2160
+    t = 17 / 30.0
+    desc = s.frame(t)
+    assert desc.n_triangles > 900_000
+    cam = scenes.orbit_camera(t, radius=30.0, height=6.0)
+
+    def rd(flags=0, tile=None, frame=17):
+        return scenes.render_desc(W, H, integrator=abi.INTEGRATOR_PATH, camera=cam, n=8, max_depth=8, bias=1e-3,
+                                  frame=frame, flags=flags, tile=tile)
+
+    with gpu.DeviceScene(desc) as ds:
+        fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        st = ds.render_device(rd(), fb.data_ptr())
+        assert st.rays_primary == W * H * 64 and st.rays_secondary > 0
+        assert torch.isfinite(fb).all() and float(fb.max()) > 0.05
+        x0, y0, w, h = 1800, 900, 96, 48           # on the middle meshes
+        want = fb[y0:y0 + h, x0:x0 + w].contiguous()
+        part = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+        counts = []
+        for flags in (0, abi.FLAG_KD_CULLED, abi.FLAG_REFERENCE_ORDER):
+            part.zero_()
+            sp = ds.render_device(rd(flags, tile=(x0, y0, w, h)), part.data_ptr())
+            counts.append((sp.rays_primary, sp.rays_secondary))
+            assert torch.equal(part.view(torch.int32), want.view(torch.int32)), flags
+        assert counts[0] == counts[1] == counts[2] and counts[0][0] == w * h * 64
+        lit = float(want.max())
+    # another frame of the sequence: the spheres moved, so the lighting of the tile changes
+    t2 = 47 / 30.0
+    desc2 = s.frame(t2)
+    with gpu.DeviceScene(desc2) as ds:
+        part2 = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+        ds.render_device(rd(tile=(x0, y0, w, h), frame=17), part2.data_ptr())
+        assert not torch.equal(part2, want)
+        assert torch.isfinite(part2).all() and lit > 0.0
