@@ -385,6 +385,29 @@ int rtx_render_device(rtx_scene* scene, const rtx_render_desc* desc, float* accu
                       rtx_stats* stats);
 
 /*
+ * rtx_render_device for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
+ * reference.  The ray queues, light-ray queues, sample slots and counters of the call live in a
+ * static device array of RTX_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until
+ * the process ends; the call allocates, creates and frees nothing, reads nothing back and does
+ * not wait: it returns once the work is queued on the scene's stream (synchronise that stream
+ * before reading accum_device).  Same image, bit for bit, as rtx_render_device.
+ * Limits: the tile is rendered as one chunk, so
+ *     768 + 272 * S + 40 * S * L + 36 * S * G   (each array rounded up to 256 bytes)
+ * must not exceed RTX_NOALLOC_SCRATCH_BYTES, with S = tile_w * tile_h * n * n sample slots, L light
+ * samples per hit (Whitted) and G gather rays per hit (GLOBAL_LIGHTING): e.g. 256 x 256 pixels at
+ * 1 spp with four light samples, or 128 x 96 at 4 spp path traced.  Larger tiles get
+ * RTX_ERR_LIMIT: split them.  Flags that need a value read back are refused with
+ * RTX_ERR_INVALID: RTX_FLAG_COUNTERS, _STAGE_TIMES, _TRACE_TIMES, _WHITTED_REFLECT,
+ * _SORT_MATERIAL, _REFILL_LANES.  No statistics are kept.  A pathTrace frame launches all
+ * max_depth levels (no early stop), so pass the depth you need.
+ * All calls on one GPU share that GPU's array: calls that overlap there (other streams, other
+ * threads, other scenes) race.  Serialise them.
+ */
+#define RTX_NOALLOC_SCRATCH_BYTES (64u << 20)
+int rtx_render_device_noalloc(rtx_scene* scene, const rtx_render_desc* desc, float* accum_device);
+
+/*
  * The present step: what the reference does to drawBuffer between a pass and the PNG.
  *   frameBuffer = drawBuffer / float(passes); with RTX_TONEMAP_CBRT each channel goes
  *   through cbrt in FP32 (Raytracer.cpp:720-725; the Whitted variant shows the buffer as

@@ -116,8 +116,10 @@ struct Workspace {
     unsigned long long* work = nullptr;     // 8 work counters, [8] shadow rays, [9] gather rays, [10..11] SIMD efficiency, [12] secondary rays
     uint32_t* host_counts = nullptr;        // pinned
     unsigned long long* host_work = nullptr;
+    bool borrowed = false;                  // laid out in memory this object does not own: nothing to free
     ~Workspace()
     {
+        if (borrowed) return;
         if (base) (void)hipFree(base);
         if (shadow_base_mem) (void)hipFree(shadow_base_mem);
         if (gather_base_mem) (void)hipFree(gather_base_mem);
@@ -140,7 +142,7 @@ T* carve(char*& p, size_t count)
 
 size_t queue_bytes(size_t cap)
 {
-    auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
+    auto al = [](size_t b) { return ((b + 255) / 256) * 256; };     // as carve() rounds
     size_t per_queue = 9 * al(cap * 8) + 3 * al(cap * 4) + al(cap * 4) + al(cap * 8);
     return 2 * per_queue + 2 * al(cap * 4) + al(cap * 3 * 8) + 6 * al(cap * 8);
 }
@@ -258,6 +260,47 @@ const float* srgb_thresholds()
     return table;
 }
 
+inline size_t al256(size_t b) { return ((b + 255) / 256) * 256; }
+size_t shadow_bytes(size_t shadow_cap) { return 5 * al256(shadow_cap * 8); }
+size_t gather_bytes(size_t gather_cap) { return 4 * al256(gather_cap * 8) + al256(gather_cap * 4); }
+
+// the three parts of a workspace laid out from p on (queue_bytes / shadow_bytes / gather_bytes long)
+void lay_out_queues(Workspace& w, char* p, size_t cap)
+{
+    for (int k = 0; k < 2; ++k) {
+        RayQueue& q = w.q[k];
+        q.ox = carve<double>(p, cap); q.oy = carve<double>(p, cap); q.oz = carve<double>(p, cap);
+        q.dx = carve<double>(p, cap); q.dy = carve<double>(p, cap); q.dz = carve<double>(p, cap);
+        q.wx = carve<double>(p, cap); q.wy = carve<double>(p, cap); q.wz = carve<double>(p, cap);
+        q.slot = carve<uint32_t>(p, cap);
+        q.branch = carve<uint32_t>(p, cap); q.counter = carve<uint32_t>(p, cap);
+        q.hit_prim = carve<int32_t>(p, cap); q.hit_depth = carve<double>(p, cap);
+    }
+    w.hit_index = carve<uint32_t>(p, cap);
+    // origins of the light rays, one per hit
+    w.sq.ox = carve<double>(p, cap); w.sq.oy = carve<double>(p, cap); w.sq.oz = carve<double>(p, cap);
+    w.gq.ox = carve<double>(p, cap); w.gq.oy = carve<double>(p, cap); w.gq.oz = carve<double>(p, cap);
+    w.perm = carve<uint32_t>(p, cap);
+    w.sample = carve<double>(p, cap * 3);
+    w.capacity = cap;
+}
+void lay_out_shadow(Workspace& w, char* p, size_t shadow_cap)
+{
+    ShadowQueue& s = w.sq;
+    s.dx = carve<double>(p, shadow_cap); s.dy = carve<double>(p, shadow_cap); s.dz = carve<double>(p, shadow_cap);
+    s.limit = carve<double>(p, shadow_cap);
+    s.hit_depth = carve<double>(p, shadow_cap);
+    w.shadow_capacity = shadow_cap;
+}
+void lay_out_gather(Workspace& w, char* p, size_t gather_cap)
+{
+    GatherQueue& g = w.gq;
+    g.dx = carve<double>(p, gather_cap); g.dy = carve<double>(p, gather_cap); g.dz = carve<double>(p, gather_cap);
+    g.hit_depth = carve<double>(p, gather_cap);
+    g.hit_prim = carve<int32_t>(p, gather_cap);
+    w.gather_capacity = gather_cap;
+}
+
 int ensure_workspace(Workspace& w, size_t cap, size_t shadow_cap, size_t gather_cap, bool with_cand)
 {
     if (!w.counts) {
@@ -274,45 +317,17 @@ int ensure_workspace(Workspace& w, size_t cap, size_t shadow_cap, size_t gather_
     if (cap > w.capacity) {
         if (w.base) { HIP_TRY(hipFree(w.base)); w.base = nullptr; w.capacity = 0; }
         HIP_TRY(hipMalloc(&w.base, queue_bytes(cap)));
-        char* p = w.base;
-        for (int k = 0; k < 2; ++k) {
-            RayQueue& q = w.q[k];
-            q.ox = carve<double>(p, cap); q.oy = carve<double>(p, cap); q.oz = carve<double>(p, cap);
-            q.dx = carve<double>(p, cap); q.dy = carve<double>(p, cap); q.dz = carve<double>(p, cap);
-            q.wx = carve<double>(p, cap); q.wy = carve<double>(p, cap); q.wz = carve<double>(p, cap);
-            q.slot = carve<uint32_t>(p, cap);
-            q.branch = carve<uint32_t>(p, cap); q.counter = carve<uint32_t>(p, cap);
-            q.hit_prim = carve<int32_t>(p, cap); q.hit_depth = carve<double>(p, cap);
-        }
-        w.hit_index = carve<uint32_t>(p, cap);
-        // origins of the light rays, one per hit
-        w.sq.ox = carve<double>(p, cap); w.sq.oy = carve<double>(p, cap); w.sq.oz = carve<double>(p, cap);
-        w.gq.ox = carve<double>(p, cap); w.gq.oy = carve<double>(p, cap); w.gq.oz = carve<double>(p, cap);
-        w.perm = carve<uint32_t>(p, cap);
-        w.sample = carve<double>(p, cap * 3);
-        w.capacity = cap;
+        lay_out_queues(w, w.base, cap);
     }
     if (shadow_cap > w.shadow_capacity) {
         if (w.shadow_base_mem) { HIP_TRY(hipFree(w.shadow_base_mem)); w.shadow_base_mem = nullptr; w.shadow_capacity = 0; }
-        auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
-        HIP_TRY(hipMalloc(&w.shadow_base_mem, 5 * al(shadow_cap * 8)));
-        char* p = w.shadow_base_mem;
-        ShadowQueue& s = w.sq;
-        s.dx = carve<double>(p, shadow_cap); s.dy = carve<double>(p, shadow_cap); s.dz = carve<double>(p, shadow_cap);
-        s.limit = carve<double>(p, shadow_cap);
-        s.hit_depth = carve<double>(p, shadow_cap);
-        w.shadow_capacity = shadow_cap;
+        HIP_TRY(hipMalloc(&w.shadow_base_mem, shadow_bytes(shadow_cap)));
+        lay_out_shadow(w, w.shadow_base_mem, shadow_cap);
     }
     if (gather_cap > w.gather_capacity) {
         if (w.gather_base_mem) { HIP_TRY(hipFree(w.gather_base_mem)); w.gather_base_mem = nullptr; w.gather_capacity = 0; }
-        auto al = [](size_t b) { return ((b + 255) / 256) * 256; };
-        HIP_TRY(hipMalloc(&w.gather_base_mem, 4 * al(gather_cap * 8) + al(gather_cap * 4)));
-        char* p = w.gather_base_mem;
-        GatherQueue& g = w.gq;
-        g.dx = carve<double>(p, gather_cap); g.dy = carve<double>(p, gather_cap); g.dz = carve<double>(p, gather_cap);
-        g.hit_depth = carve<double>(p, gather_cap);
-        g.hit_prim = carve<int32_t>(p, gather_cap);
-        w.gather_capacity = gather_cap;
+        HIP_TRY(hipMalloc(&w.gather_base_mem, gather_bytes(gather_cap)));
+        lay_out_gather(w, w.gather_base_mem, gather_cap);
     }
     const size_t cand_cap = with_cand ? std::max(cap, std::max(shadow_cap, gather_cap)) : 0;
     if (cand_cap > w.cand_capacity) {
@@ -411,6 +426,33 @@ inline dim3 trace_grid_for(size_t n) { return dim3((unsigned)((n + kTraceBlock -
 
 }  // namespace
 
+// Scratch memory for rtx_render_device_noalloc: one chunk's ray queues, light-ray queues, sample
+// slots and counters live here instead of in memory the call would have to allocate.  Every
+// device the code object is loaded on holds its own copy at its own address; the name below is
+// a host-side stand-in, never a device address: host code uses the pointer that
+// hipGetSymbolAddress returned for the device (static_scratch()).
+static __device__ __align__(256) unsigned char scratch[RTX_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::atomic<unsigned char*> g_scratch_ptr[kMaxDevices];
+
+// the device's copy of `scratch`; the device must be current
+int static_scratch(int device, unsigned char** out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(RTX_ERR_LIMIT, "device %d: at most %d devices", device, kMaxDevices);
+    unsigned char* p = g_scratch_ptr[device].load();
+    if (!p) {
+        HIP_TRY(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(RTX_ERR_DEVICE, "hipGetSymbolAddress returned a null address for the scratch array");
+        g_scratch_ptr[device].store(p);
+    }
+    *out = p;
+    return RTX_OK;
+}
+constexpr size_t kScratchHeader = 3 * 256;      // queue-length ring, work counters, histogram bins
+}  // namespace
+
 // fn(lo, hi) over [0, n) in a few contiguous pieces, each on a thread of its own
 template <class F>
 static void in_pieces(uint32_t n, F fn)
@@ -447,7 +489,9 @@ int rtx_init(int device)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RTX_ERR_NO_GPU, "device %d is %s; this library is built for gfx950 only", cur, prop.gcnArchName);
     g_device.store(cur);
-    return RTX_OK;
+    // the device's copy of the allocation-free entry point's scratch array, looked up once
+    unsigned char* scratch_ptr = nullptr;
+    return static_scratch(cur, &scratch_ptr);
 }
 
 int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
@@ -899,8 +943,12 @@ static int launch_trace(rtx_scene* sc, Workspace& ws, hipStream_t stream, const 
     return RTX_OK;
 }
 
-int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rtx_stats* stats)
+// fixed_scratch == nullptr: rtx_render_device.  Otherwise rtx_render_device_noalloc: the tile is one
+// chunk whose workspace is laid out in that memory, everything is queued on the scene's stream and
+// nothing is allocated, created, read back or waited for.
+static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rtx_stats* stats, unsigned char* fixed_scratch)
 {
+    const bool fixed = fixed_scratch != nullptr;
     if (!sc || !rd || !accum) return fail(RTX_ERR_INVALID, "null argument");
     if (rd->integrator > RTX_INTEGRATOR_WHITTED) return fail(RTX_ERR_INVALID, "unknown integrator");
     USE_DEVICE(sc->device);
@@ -971,7 +1019,8 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     // even with equal sizes.  Small tiles stay in one piece: halves would only make the tails longer.
     uint64_t two_lane_min = 1u << 20;       // sample slots in the tile
     if (const char* env = std::getenv("RTX_TWO_LANE_MIN")) { long v = std::atol(env); if (v >= 128) two_lane_min = (uint64_t)v; }
-    const bool serial = (rd->flags & RTX_FLAG_SERIAL_CHUNKS) != 0 || padded_pixels * nn < two_lane_min;
+    if (fixed) pixels_per_chunk = padded_pixels;         // one chunk, or RTX_ERR_LIMIT below
+    const bool serial = fixed || (rd->flags & RTX_FLAG_SERIAL_CHUNKS) != 0 || padded_pixels * nn < two_lane_min;
     if (!serial) {
         const uint64_t half = std::max<uint64_t>(64, pixels_per_chunk / 2 / 64 * 64);
         uint64_t n_chunks = (padded_pixels + half - 1) / half;
@@ -985,9 +1034,35 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     if (queue_cap * std::max<uint64_t>(gather_per_hit0, 1) > 0xf0000000ull || queue_cap * (uint64_t)std::max<uint32_t>(shadow_per_hit, 1) > 0xf0000000ull)
         return fail(RTX_ERR_LIMIT, "light-ray queue of the smallest chunk exceeds 2^32 entries (%u shadow rays per hit)", shadow_per_hit);
     int rc = RTX_OK;
-    for (int k = 0; k < n_lanes; ++k) {
-        rc = ensure_workspace(sc->ws[k], queue_cap, whitted ? queue_cap * std::max<uint32_t>(shadow_per_hit, 1) : 0,
-                              (size_t)(queue_cap * gather_per_hit0), (rd->flags & RTX_FLAG_REFILL_LANES) != 0);
+    const size_t shadow_cap = whitted ? queue_cap * std::max<uint32_t>(shadow_per_hit, 1) : 0;
+    const size_t gather_cap = (size_t)(queue_cap * gather_per_hit0);
+    Workspace fixed_ws;
+    if (fixed) {
+        if (rd->flags & (RTX_FLAG_WHITTED_REFLECT | RTX_FLAG_SORT_MATERIAL | RTX_FLAG_REFILL_LANES | RTX_FLAG_COUNTERS |
+                         RTX_FLAG_STAGE_TIMES | RTX_FLAG_TRACE_TIMES))
+            return fail(RTX_ERR_INVALID, "rtx_render_device_noalloc: flags 0x%x need queue lengths, counters or times read back",
+                        rd->flags);
+        const size_t need = kScratchHeader + queue_bytes(queue_cap) + shadow_bytes(shadow_cap) + gather_bytes(gather_cap);
+        if (need > (size_t)RTX_NOALLOC_SCRATCH_BYTES)
+            return fail(RTX_ERR_LIMIT, "rtx_render_device_noalloc: %zu sample slots with %u light rays per hit need %zu bytes of "
+                        "scratch, the static array holds %zu: render smaller tiles", queue_cap, shadow_per_hit, need,
+                        (size_t)RTX_NOALLOC_SCRATCH_BYTES);
+        fixed_ws.borrowed = true;
+        char* p = reinterpret_cast<char*>(fixed_scratch);
+        fixed_ws.counts = carve<uint32_t>(p, 8);
+        fixed_ws.work = carve<unsigned long long>(p, 16);
+        fixed_ws.bins = carve<uint32_t>(p, 2 * kBins);
+        lay_out_queues(fixed_ws, p, queue_cap);
+        p += queue_bytes(queue_cap);
+        lay_out_shadow(fixed_ws, p, shadow_cap);
+        p += shadow_bytes(shadow_cap);
+        lay_out_gather(fixed_ws, p, gather_cap);
+        // the array keeps the last call's contents: the counters start at zero (the ring of queue
+        // lengths and the sample slots are cleared by the chunk's first launch, as always)
+        HIP_TRY(hipMemsetAsync(fixed_scratch, 0, kScratchHeader, sc->stream));
+    }
+    for (int k = 0; k < n_lanes && !fixed; ++k) {
+        rc = ensure_workspace(sc->ws[k], queue_cap, shadow_cap, gather_cap, (rd->flags & RTX_FLAG_REFILL_LANES) != 0);
         if (rc != RTX_OK) return rc;
     }
     if (n_lanes > 1 && !sc->lane_stream[0]) {
@@ -1000,7 +1075,11 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     hipStream_t user = sc->stream;
 
     if (sc->async && stats) return fail(RTX_ERR_INVALID, "asynchronous scene: statistics come from rtx_scene_wait");
-    rtx_stats& local = sc->pending;
+    rtx_stats unkept;
+    std::memset(&unkept, 0, sizeof unkept);
+    rtx_stats& local = fixed ? unkept : sc->pending;
+    // neither an asynchronous scene nor the allocation-free call ever waits for a queue length
+    const bool never_wait = sc->async || fixed;
     struct Events {
         hipEvent_t a = nullptr, b = nullptr;
         ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
@@ -1008,7 +1087,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     hipEvent_t& ev0 = ev.a;
     hipEvent_t& ev1 = ev.b;
     if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, user)); }
-    const bool keep_times = stats != nullptr || sc->async;
+    const bool keep_times = !fixed && (stats != nullptr || sc->async);
     if (n_lanes > 1) HIP_TRY(hipEventRecord(sc->fork_event, user));
 
     // rayTrace spawns nothing when no material refracts and the mirror extension is off
@@ -1051,7 +1130,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     Lane lanes[2];
     for (int k = 0; k < n_lanes; ++k) {
         Lane& L = lanes[k];
-        L.w = &sc->ws[k];
+        L.w = fixed ? &fixed_ws : &sc->ws[k];
         L.st = n_lanes > 1 ? sc->lane_stream[k] : user;
         L.timer_p = &sc->lane_timer[k];
         L.trace_timer_p = &sc->lane_trace_timer[k];
@@ -1172,7 +1251,7 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
         L.level = level + 1;
         // an asynchronous scene never waits for a short level: other frames are in flight and the
         // launches of a level that turns out empty cost less than holding up the host
-        if (sync_every_level || bound >= kLongLevel || (level % 4 == 3 && !sc->async)) {
+        if (!fixed && (sync_every_level || bound >= kLongLevel || (level % 4 == 3 && !never_wait))) {
             HIP_TRY(hipMemcpyAsync(w.host_counts, next_len, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             L.want_sync = true;
         } else {
@@ -1240,14 +1319,14 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     }
     for (int k = 0; k < n_lanes; ++k) {
         Lane& L = lanes[k];
-        if (!sc->async) HIP_TRY(enqueue_work_readback(*L.w, L.st));
+        if (!never_wait) HIP_TRY(enqueue_work_readback(*L.w, L.st));
         if (n_lanes > 1) {
             HIP_TRY(hipEventRecord(sc->join_event[k], L.st));
             HIP_TRY(hipStreamWaitEvent(user, sc->join_event[k], 0));
         }
     }
     drain.armed = false;        // from here the caller's stream waits for the lanes
-    if (sc->async) return RTX_OK;
+    if (never_wait) return RTX_OK;
     if (stats) HIP_TRY(hipEventRecord(ev1, user));
     HIP_TRY(hipStreamSynchronize(user));
     if (stats) {
@@ -1257,6 +1336,21 @@ int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rt
     }
     hand_out_stats(sc, stats);
     return RTX_OK;
+}
+
+int rtx_render_device(rtx_scene* sc, const rtx_render_desc* rd, float* accum, rtx_stats* stats)
+{
+    return render_impl(sc, rd, accum, stats, nullptr);
+}
+
+int rtx_render_device_noalloc(rtx_scene* sc, const rtx_render_desc* rd, float* accum)
+{
+    if (!sc) return fail(RTX_ERR_INVALID, "null argument");
+    USE_DEVICE(sc->device);
+    unsigned char* ptr = nullptr;
+    int rc = static_scratch(sc->device, &ptr);
+    if (rc != RTX_OK) return rc;
+    return render_impl(sc, rd, accum, nullptr, ptr);
 }
 
 int rtx_scene_set_async(rtx_scene* sc, int enabled)

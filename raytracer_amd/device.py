@@ -21,7 +21,7 @@ PD = C.POINTER(C.c_double)
 # every symbol include/rtx.h declares
 EXPORTS = ["rtx_init", "rtx_device_count", "rtx_scene_create", "rtx_scene_set_stream", "rtx_scene_destroy",
            "rtx_scene_set_async", "rtx_scene_wait", "rtx_scene_clone",
-           "rtx_trace_closest", "rtx_render", "rtx_render_device", "rtx_present", "rtx_present_device", "rtx_uniform",
+           "rtx_trace_closest", "rtx_render", "rtx_render_device", "rtx_render_device_noalloc", "rtx_present", "rtx_present_device", "rtx_uniform",
            "rtx_last_error"]
 
 
@@ -51,6 +51,7 @@ def lib():
         C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
     L.rtx_render.argtypes = [C.c_void_p, C.POINTER(abi.RenderDesc), C.POINTER(C.c_float), C.POINTER(abi.Stats)]
     L.rtx_render_device.argtypes = [C.c_void_p, C.POINTER(abi.RenderDesc), C.c_void_p, C.POINTER(abi.Stats)]
+    L.rtx_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(abi.RenderDesc), C.c_void_p]
     L.rtx_present.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                               C.POINTER(C.c_uint8)]
     L.rtx_present_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
@@ -169,6 +170,11 @@ class DeviceScene:
         _check(self._L.rtx_render_device(self._h, C.byref(rd), C.c_void_p(accum_ptr),
                                          C.byref(stats) if want_stats else None))
         return stats
+
+    def render_device_noalloc(self, rd, accum_ptr):
+        """rtx_render_device_noalloc: queued on the scene's stream, nothing allocated, nothing
+        returned; the caller synchronises the stream before reading the framebuffer."""
+        _check(self._L.rtx_render_device_noalloc(self._h, C.byref(rd), C.c_void_p(accum_ptr)))
 
     def present(self, accum, passes=1, tonemap=abi.TONEMAP_CBRT, flip=True):
         """rtx_present: [H, W, 3] float accumulation buffer (row 0 = bottom) -> [H, W, 3] uint8 sRGB."""
