@@ -140,3 +140,47 @@ def present(accum, passes=1, tonemap=1, flip=True):
 
 def uniform(seed, frame, pixel, sample, branch, draw):
     return lib().orc_uniform(seed, frame, pixel, sample, branch, draw)
+
+
+_kd_lib = None
+
+
+def build_kd(box_min, box_max, scene_min, scene_max):
+    """The reference's buildKDTree (oracle/kd_oracle.cpp) over shapes 0..n-1 given by their
+    bounding boxes ([n,3] each; mid = (min + max) / 2.0 as AABB's two-argument constructor sets
+    it, Shape.hpp:17-28), flattened in pre-order.  Returns a dict of the rtx_scene_desc KD arrays."""
+    global _kd_lib
+    if _kd_lib is None:
+        path = os.path.join(_HERE, "libkd_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make -C oracle`")
+        K = C.CDLL(path)
+        K.orc_kd_build.restype = C.c_void_p
+        K.orc_kd_build.argtypes = [C.c_uint32, PD, PD, PD, PD, PD]
+        K.orc_kd_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        K.orc_kd_copy.argtypes = [C.c_void_p, PD, PD, PD] + [C.POINTER(C.c_int32)] * 3 + [C.POINTER(C.c_uint32)] * 3
+        K.orc_kd_free.argtypes = [C.c_void_p]
+        _kd_lib = K
+    K = _kd_lib
+    box_min, pmin = _in(box_min)
+    box_max, pmax = _in(box_max)
+    mid, pmid = _in((box_min + box_max) / 2.0)
+    _, psmin = _in(scene_min)
+    _, psmax = _in(scene_max)
+    h = C.c_void_p(K.orc_kd_build(box_min.size // 3, pmin, pmax, pmid, psmin, psmax))
+    counts = (C.c_int64 * 5)()
+    K.orc_kd_counts(h, counts)
+    nb, nl, nr, depth, root = list(counts)
+    out = dict(branch_min=np.zeros(nb * 3), branch_max=np.zeros(nb * 3), branch_value=np.zeros(nb),
+               branch_axis=np.zeros(nb, np.int32), branch_lesser=np.zeros(nb, np.int32), branch_greater=np.zeros(nb, np.int32),
+               leaf_first=np.zeros(nl, np.uint32), leaf_count=np.zeros(nl, np.uint32), leaf_refs=np.zeros(nr, np.uint32))
+    i32, u32 = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    K.orc_kd_copy(h, out["branch_min"].ctypes.data_as(PD), out["branch_max"].ctypes.data_as(PD),
+                  out["branch_value"].ctypes.data_as(PD), out["branch_axis"].ctypes.data_as(i32),
+                  out["branch_lesser"].ctypes.data_as(i32), out["branch_greater"].ctypes.data_as(i32),
+                  out["leaf_first"].ctypes.data_as(u32), out["leaf_count"].ctypes.data_as(u32),
+                  out["leaf_refs"].ctypes.data_as(u32))
+    K.orc_kd_free(h)
+    out["root"] = root
+    out["depth"] = depth
+    return out

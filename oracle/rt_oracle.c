@@ -964,6 +964,16 @@ int orc_sphere_hit(const double center[3], double r2, const double nmat[16], con
     return ok;
 }
 
+/* the `entering` test of pathTrace / rayTrace for a given dot(normal, inverseDirection):
+   normal = (x, 0, 0), inverseDirection = (1, 0, 0) */
+int orc_entering_for_dot(double x)
+{
+    ray_t r;
+    memset(&r, 0, sizeof r);
+    r.inverse_direction = V(1.0, 0.0, 0.0);
+    return is_entering(V(x, 0.0, 0.0), &r);
+}
+
 void orc_refraction_ray(const double n[3], const double d[3], double ior, int entering, double out[3], int* internal_only)
 {
     int io = 0;

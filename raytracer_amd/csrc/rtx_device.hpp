@@ -517,10 +517,19 @@ RTX_DEV d3 cook_torrance(d3 vi, d3 vo, d3 vn, double smooth, d3 down, d3 F0, d3&
     return (((down * geo) * fres) * sinT) / denom;
 }
 
+// entering = acos(dot(normal, inverseDirection)) < pi / 2.0 (Raytracer.cpp:248-249).  The quotient
+// pi / 2.0 is the double P just BELOW the real pi/2 (by 6.1e-17), and acos(x) = pi/2 - x - ...
+// rounds to P or above for every x up to half a unit in the last place beyond that gap: the
+// comparison is true exactly for x >= kEnteringMin = 1.7225464241988333e-16 and x <= 1 (beyond 1,
+// as for NaN, acos gives NaN and the comparison is false; the normal of a triangle is not
+// normalised, Triangle.cpp:57-60, so |x| > 1 occurs).  That threshold was found by bisection on the
+// C library's acos and checked on every double within two million places of it
+// (tests/test_oracle_kat.py sweeps the bracket against the oracle, which calls acos).
+constexpr double kEnteringMin = 1.7225464241988333e-16;     // bits 0x3ca8d313198a2e04
 RTX_DEV bool is_entering(d3 normal, d3 ray_inv_dir)
 {
-    double angle = acos(dot(normal, ray_inv_dir));
-    return angle < (kPi / 2.0);
+    const double x = dot(normal, ray_inv_dir);
+    return x >= kEnteringMin && x <= 1.0;
 }
 
 }  // namespace rtx

@@ -201,9 +201,9 @@ class HostScene:
 
     def set_kd_builder(self, builder="flat", threads=0):
         """'flat': the tree is built straight into the flattened arrays, on `threads` threads
-        (0 = automatic); 'reference': buildKDTree's KDNode objects and a flattening walk, as
-        the reference builds it.  Both give the same arrays."""
-        self._L.rth_set_kd_builder(self._h, {"flat": 0, "reference": 1}[builder], int(threads))
+        (0 = automatic); 'nodes': through buildKDTree's KDNode objects and a flattening walk, the
+        way a driver written against the reference's classes gets it.  Both give the same arrays."""
+        self._L.rth_set_kd_builder(self._h, {"flat": 0, "nodes": 1}[builder], int(threads))
 
     def kd_stats(self):
         out = (C.c_uint32 * 5)()

@@ -24,7 +24,7 @@ struct rth_scene {
     AABB sceneBox;
     std::string error;
     double timings[4] = {0, 0, 0, 0};      // seconds: redoAABBs, buildKDTree, flatten, freeing the old tree
-    int builder = 0;                        // 0: buildFlatKD; 1: buildKDTree + flattening walk
+    int builder = 0;                        // 0: buildFlatKD; 1: buildKDTree's node objects + flattening walk
     int threads = 0;
 };
 
@@ -242,7 +242,7 @@ const rtx_scene_desc* rth_frame(rth_scene* s, double current_time) {
     }
 }
 
-// builder 0: buildFlatKD (default), 1: buildKDTree + flattening walk; threads <= 0: automatic
+// builder 0: buildFlatKD (default), 1: buildKDTree's node objects + flattening walk; threads <= 0: automatic
 void rth_set_kd_builder(rth_scene* s, int builder, int threads) { s->builder = builder; s->threads = threads; }
 
 // branches, leaves, leaf refs, depth, largest leaf of the last rth_frame

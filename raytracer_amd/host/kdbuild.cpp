@@ -1,8 +1,9 @@
-// kdbuild.cpp -- buildKDTree (KDTree.cpp:68-126) straight into the flattened arrays.
+// kdbuild.cpp -- the reference's KD tree (construction rules of KDTree.cpp:68-126) built
+// straight into the flattened arrays.
 //
-// Produces exactly the tree that buildKDTree() + the flattener's pre-order walk produce
-// (same branches, same leaf contents in the same order, same numbering), several times
-// faster:
+// Produces exactly the tree that the reference's recursion with stable sorts and a pre-order
+// flattening walk produce (same branches, same leaf contents in the same order, same
+// numbering; tests check it against a restatement of that recursion), several times faster:
 //   * the node's two std::stable_sort calls over Shape* with a comparator that chases
 //     pointers become sorts of compact (key, key, position, id) records.  Stable sorts
 //     compose: after "sort by min, then stable sort by max" the order is lexicographic in
@@ -164,7 +165,8 @@ struct Builder {
 
 }  // namespace
 
-void buildFlatKD(const std::vector<Shape*>& shapes, const AABB& box, FlatKD& out, int threads) {
+void buildFlatKD(const std::vector<Shape*>& shapes, const AABB& box, FlatKD& out, int threads, Axis axis,
+                 int recursionWithoutChange, int layer) {
     out = FlatKD();
     BoxTable t;
     const size_t n = shapes.size();
@@ -182,7 +184,7 @@ void buildFlatKD(const std::vector<Shape*>& shapes, const AABB& box, FlatKD& out
         spawnLayers += 2;                   // more tasks than threads: subtrees differ in size
     }
     Builder b{t, spawnLayers};
-    out.root = b.build(out, std::move(ids), box, X, 0, 0);
+    out.root = b.build(out, std::move(ids), box, axis, recursionWithoutChange, layer);
     out.stats.branches = (uint32_t)out.value.size();
     out.stats.leaves = (uint32_t)out.leafFirst.size();
     out.stats.leafRefs = (uint32_t)out.leafRefs.size();

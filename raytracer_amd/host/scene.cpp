@@ -171,57 +171,31 @@ rtx_light SquareLight::flatten() const {
     return l;
 }
 
-// ---- KD construction, KDTree.cpp:45-126 -----------------------------------------
-static void sortShapesMax(std::vector<Shape*>& shapes, Axis axis) {
-    std::stable_sort(shapes.begin(), shapes.end(), [axis](Shape* a, Shape* b) {
-        return b->boundingBox.max[axis] > a->boundingBox.max[axis];
-    });
+// ---- KD construction ---------------------------------------------------------------
+// buildKDTree(shapes, box) of KDTree.hpp with the reference's node classes as the result.  The
+// tree itself comes from buildFlatKD (kdbuild.cpp), which defines it; here its flat arrays are
+// turned back into KDBranch / KDLeaf objects for callers that want to walk pointers.
+namespace {
+KDNode* inflate(const FlatKD& kd, int32_t node, const std::vector<Shape*>& shapes) {
+    if (node < 0) {
+        const uint32_t leaf = (uint32_t)~node;
+        std::vector<Shape*> held;
+        held.reserve(kd.leafCount[leaf]);
+        for (uint32_t r = 0; r < kd.leafCount[leaf]; ++r) held.push_back(shapes[kd.leafRefs[kd.leafFirst[leaf] + r]]);
+        return new KDLeaf(std::move(held));
+    }
+    AABB area;
+    for (int k = 0; k < 3; ++k) { area.min[k] = kd.bmin[3 * (size_t)node + k]; area.max[k] = kd.bmax[3 * (size_t)node + k]; }
+    KDNode* lesser = inflate(kd, kd.lesser[node], shapes);
+    KDNode* greater = inflate(kd, kd.greater[node], shapes);
+    return new KDBranch(greater, lesser, area, Axis(kd.axis[node]), kd.value[node]);
 }
-static void sortShapesMin(std::vector<Shape*>& shapes, Axis axis) {
-    std::stable_sort(shapes.begin(), shapes.end(), [axis](Shape* a, Shape* b) {
-        return b->boundingBox.min[axis] > a->boundingBox.min[axis];
-    });
-}
+}  // namespace
 
-// (Building subtrees concurrently -- std::async or OpenMP tasks -- was tried and is slower
-// than this serial form: the work is dominated by allocating and copying shape lists.)
 KDNode* buildKDTree(std::vector<Shape*> shapes, AABB box, Axis axis, int recursionWithoutChange, int layer) {
-    if (shapes.size() < 7 || recursionWithoutChange > 3 || layer > 20) return new KDLeaf(shapes);
-    double value = shapes.at(shapes.size() / 2u)->boundingBox.mid[axis];
-    Axis nextAxis = Axis((axis + 1) % 3);
-
-    size_t maxLesserIndex = 0;
-    sortShapesMin(shapes, axis);
-    while (maxLesserIndex < shapes.size() && shapes.at(maxLesserIndex)->boundingBox.min[axis] <= value)
-        maxLesserIndex++;
-    KDNode* lesserNode = nullptr;
-    if (maxLesserIndex > 0) {
-        std::vector<Shape*> lesserShapes(shapes.begin(), shapes.begin() + maxLesserIndex);
-        AABB lesserBox = box;
-        lesserBox.max[axis] = value;
-        int newRWC = 0;
-        if (lesserShapes.size() == shapes.size()) newRWC = recursionWithoutChange + 1;
-        lesserNode = buildKDTree(std::move(lesserShapes), lesserBox, nextAxis, newRWC, layer + 1);
-    } else {
-        lesserNode = new KDLeaf({});
-    }
-
-    int minGreaterIndex = (int)shapes.size() - 1;
-    sortShapesMax(shapes, axis);
-    while (minGreaterIndex > 0 && shapes.at(minGreaterIndex)->boundingBox.max[axis] >= value)
-        minGreaterIndex--;
-    KDNode* greaterNode = nullptr;
-    if (minGreaterIndex < (int)(shapes.size() - 1)) {
-        std::vector<Shape*> greaterShapes(shapes.begin() + minGreaterIndex, shapes.end());
-        AABB greaterBox = box;
-        greaterBox.min[axis] = value;
-        int newRWC = 0;
-        if (greaterShapes.size() == shapes.size()) newRWC = recursionWithoutChange + 1;
-        greaterNode = buildKDTree(std::move(greaterShapes), greaterBox, nextAxis, newRWC, layer + 1);
-    } else {
-        greaterNode = new KDLeaf({});
-    }
-    return new KDBranch(greaterNode, lesserNode, box, axis, value);
+    FlatKD kd;
+    buildFlatKD(shapes, box, kd, 0, axis, recursionWithoutChange, layer);
+    return inflate(kd, kd.root, shapes);
 }
 
 AABB redoAABBs(FrameInfo& fi) {

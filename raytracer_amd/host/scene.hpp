@@ -241,9 +241,10 @@ public:
     std::vector<Shape*> shapes;
 };
 
-// KDTree.cpp:68-126.  The reference sorts with std::sort, whose order among equal
-// keys is unspecified; this uses std::stable_sort so the tree is a function of
-// the input order alone.
+// buildKDTree of KDTree.hpp:57 (construction rules of KDTree.cpp:68-126).  The reference sorts
+// with std::sort, whose order among equal keys is unspecified; here equal keys keep their
+// incoming order, so the tree is a function of the input order alone.  The tree is built by
+// buildFlatKD below and handed back as node objects.
 KDNode* buildKDTree(std::vector<Shape*> shapes, AABB box, Axis axis = X,
                     int recursionWithoutChange = 0, int layer = 0);
 
@@ -276,7 +277,9 @@ struct FlatKD {
 
 // buildKDTree + flattening in one step: the same tree, built from compact records and on
 // several threads (threads <= 0: one per core, at most 16).  See kdbuild.cpp.
-void buildFlatKD(const std::vector<Shape*>& shapes, const AABB& box, FlatKD& out, int threads = 0);
+// axis / recursionWithoutChange / layer: the state of the reference's recursion to start from.
+void buildFlatKD(const std::vector<Shape*>& shapes, const AABB& box, FlatKD& out, int threads = 0, Axis axis = X,
+                 int recursionWithoutChange = 0, int layer = 0);
 
 // Owns the SoA arrays an rtx_scene_desc points into.
 class FlatScene {

@@ -144,9 +144,10 @@ def _kd_arrays(scene, desc):
 
 @pytest.mark.parametrize("name", ["live", "whitted", "lens", "mesh", "ties", "animated"])
 def test_flat_kd_builder_equals_buildkdtree(name):
-    """buildFlatKD (compact records, partial sorts, threads) must give exactly the arrays that
-    buildKDTree + the flattening walk give: same branches, same leaf contents in the same
-    order, same numbering, whatever the number of threads."""
+    """buildFlatKD (compact records, partial sorts, threads) and buildKDTree's node objects run
+    through the flattening walk must give exactly the arrays the reference's construction gives
+    (restated in oracle/kd_oracle.cpp): same branches, same leaf contents in the same order, same
+    numbering, whatever the number of threads."""
     from raytracer_amd import scenes, host
 
     def make():
@@ -173,14 +174,24 @@ def test_flat_kd_builder_equals_buildkdtree(name):
         s.triangles(pos, nrm, uv, m)
         return s, 0.0
 
+    from oracle import binding as orc
     got = {}
-    for builder, threads in (("reference", 0), ("flat", 1), ("flat", 3), ("flat", 8)):
+    for builder, threads in (("nodes", 0), ("flat", 1), ("flat", 3), ("flat", 8)):
         scene, t = make()
         scene.set_kd_builder(builder, threads)
-        got[(builder, threads)] = _kd_arrays(scene, scene.frame(t))
-    ref = got[("reference", 0)]
+        desc = scene.frame(t)
+        got[(builder, threads)] = _kd_arrays(scene, desc)
+    # the reference's recursion (KDTree.cpp:68-126) restated on the same shape boxes
+    n = desc.n_shapes
+    bmin = host.desc_array(desc, "prim_aabb_min", 3 * n, np.float64).reshape(n, 3)
+    bmax = host.desc_array(desc, "prim_aabb_max", 3 * n, np.float64).reshape(n, 3)
+    smin, smax = scene.scene_box()
+    ref = orc.build_kd(bmin, bmax, smin, smax)
     for key, arrays in got.items():
+        assert arrays["stats"]["depth"] == ref["depth"], key
         for field, want in ref.items():
+            if field == "depth":
+                continue
             have = arrays[field]
             same = np.array_equal(want, have) if isinstance(want, np.ndarray) else want == have
             assert same, (key, field)
