@@ -3,23 +3,29 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): a 60 026-triangle mesh scene (seeded
-procedural stand-in for the reference's FBX meshes) through the reference's KD
-tree, Whitted integrator with one DirectionalLight: primary + hard shadow rays,
-1920x1080, 1 sample per pixel.  A step is one frame of an orbiting camera
-(t = frame/30): rtx_render_device into a float framebuffer resident in HBM,
-then rtx_present_device (what the reference does between drawBuffer and the PNG:
-8-bit sRGB, flipped).  The frames of the sequence are independent, so a rank keeps
---in-flight of them (default 4) queued on as many streams, each through its own handle
-on the one device copy of the scene (rtx_scene_clone) with its own framebuffers: the
-tail of one frame's launches is filled by the next frames' kernels.  With N > 1 ranks every rank renders and presents its own
-frame of the sequence (frames are independent given the read-only scene) and
-the N presented frames are gathered to rank 0 with RCCL inside the timed
-region, as a frame driver that writes the PNGs on rank 0 needs them; per-GPU
-work is fixed, so scaling is weak.
+Headline workload (BASELINE.json configs[1]): the reference's backpack model (67 908 triangles,
+Raytracer/Models/backpack/backpack.fbx read by the library's FBX reader and stored as a fixture) plus a
+two-triangle floor through the reference's KD tree, Whitted integrator with one DirectionalLight:
+primary + hard shadow rays, 1920x1080, 1 sample per pixel (the scene of Raytracer-noah-laptop.cpp:597-611,
+orbit camera of :672).  A step is one frame of the orbiting camera (t = frame/30): rtx_render_device
+into a float framebuffer resident in HBM, then rtx_present_device (what the reference does between
+drawBuffer and the PNG: 8-bit sRGB, flipped).  The frames of the sequence are independent, so a rank
+keeps --in-flight of them (default 4) queued on as many streams, each through its own handle on the one
+device copy of the scene (rtx_scene_clone).  With N > 1 ranks every rank renders and presents its own
+frames and the presented frames are gathered to rank 0 with RCCL inside the timed region; per-GPU work
+is fixed, so `value` scales weakly.
+
+The second half of the metric -- ms per 1080p 16-spp frame -- is measured on two frames of
+BASELINE.json configs[3], each a first-class object of the line with its own roofline and CPU
+baseline: `frame_16spp.whitted_area_light` (GGX-parameter mesh, texture + checker sampling, SquareLight
+soft shadows, rayTrace) and `frame_16spp.path_ggx` (the same mesh under pathTrace: CookTorance / GGX Gp
+bounces lit by an emissive sphere).  With N > 1 one frame is split over the ranks in interleaved groups of
+rows (strong scaling) and the presented rows are gathered on rank 0.
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
-  roofline      algorithmic bytes of the traversal kernel / its measured duration
+  roofline      the traversal kernel against the roof it is under (VALU issue), with the HBM and L2
+                figures beside it; counter-based entries come from profiles/counters.json, which names
+                the rocprofv3 run they were collected in
   cpu_baseline  the CPU oracle timed on a bounded sample of the same workload
 """
 import argparse
@@ -35,11 +41,116 @@ import numpy as np  # noqa: E402
 
 WIDTH, HEIGHT = 1920, 1080
 HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0           # aggregate L2 bandwidth of the eight XCDs
 FP64_PEAK_TFLOPS = 78.6
+CLOCK_GHZ = 2.4
+SIMDS = 256 * 4
+# a wave64 VALU instruction occupies its SIMD (16 lanes wide) for four cycles
+VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / 4.0
+
+TRACE_KERNELS = {
+    "bvh": "k_trace_pool<false,3> (closest hit) and <false,4> (any hit): BVH candidates + KD membership verification",
+    "kd-culled": "k_trace_pool<false,1> (closest hit) and <false,2> (any hit): culled walk of the reference's KD tree",
+    "reference": "k_trace_pool<false,0>: the reference's KD walk, node for node",
+}
 
 
 def frame_time(step, rank, world):
     return (step * world + rank) / 30.0
+
+
+def load_counters():
+    """profiles/counters.json: per workload and kernel, the mean counter values per launch and the
+    launches per frame, from rocprofv3 --pmc passes of this script (tools/profile_pmc.sh).  None when
+    the file is absent."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+def counter_figures(counters, workload, walk, ms_per_frame, dominant):
+    """Counter-based entries of a roofline block: VALU wave-instructions and HBM / L2 bytes per frame
+    (all kernels of a frame) against the frame time measured in THIS run, and the HBM traffic per launch
+    of the dominant kernel.  The counters were collected with kernels serialised by the profiler; the
+    instruction and byte counts of a frame do not depend on that, the time does not come from there."""
+    if not counters or walk != "bvh":
+        return None
+    w = counters.get("workloads", {}).get(workload)
+    if not w:
+        return None
+    valu = hbm = l2 = lanes = 0.0
+    dom_traffic, dom_launches = 0.0, 0.0
+    for name, k in w["kernels"].items():
+        per_frame = k["launches_per_frame"]
+        valu += per_frame * k.get("SQ_INSTS_VALU", 0.0)
+        lanes += per_frame * k.get("SQ_THREAD_CYCLES_VALU", 0.0)
+        bytes_ = (2.0 * k.get("FETCH_SIZE", 0.0) + k.get("WRITE_SIZE", 0.0)) * 1024.0
+        hbm += per_frame * bytes_
+        l2 += per_frame * k.get("TCC_REQ_sum", 0.0) * 128.0
+        if any(d in name for d in dominant):
+            dom_traffic += per_frame * bytes_
+            dom_launches += per_frame
+    s = ms_per_frame / 1e3
+    out = {
+        "valu_winst_per_frame": round(valu),
+        "valu_ginst_per_s": round(valu / s / 1e9, 2),
+        "valu_frac": round(valu / s / 1e9 / VALU_PEAK_GINST, 4),
+        "active_lane_frac": round(lanes / (valu * 64.0), 3) if valu else None,
+        "hbm_bytes_per_frame": round(hbm),
+        "hbm_gbs": round(hbm / s / 1e9, 1),
+        "hbm_frac": round(hbm / s / 1e9 / HBM_PEAK_GBS, 4),
+        "l2_request_bytes_per_frame": round(l2),
+        "l2_gbs": round(l2 / s / 1e9, 1),
+        "l2_frac": round(l2 / s / 1e9 / L2_PEAK_GBS, 4),
+        "traffic_per_launch": round(dom_traffic / dom_launches) if dom_launches else None,
+        "source": counters.get("source"),
+    }
+    return out
+
+
+def roofline_block(walk, alg_bytes, rays, ms_trav, launches, ms_per_frame, cf, serial=None, overlap=False, flops=None):
+    """The roofline object of one workload.  `bound` is VALU issue: the walk's nodes and shapes come
+    out of L1 / L2 / Infinity Cache (HBM traffic is a few percent of the algorithmic bytes), and what a
+    frame's time buys is wave-level VALU instructions -- `achieved`, when the counters are at hand,
+    is those of ALL kernels of a frame over the frame time of this run, so frac <= 1 holds at step
+    level.  The HBM view the metric's definition asks for is kept under `hbm`: algorithmic bytes per
+    launch over the launch duration measured live with HIP events on the kernel's stream."""
+    avg_launch_s = (ms_trav / 1e3) / max(launches, 1)
+    bytes_per_launch = alg_bytes / max(launches, 1)
+    hbm_achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    r = {
+        "bound": "valu-issue",
+        "achieved": cf["valu_ginst_per_s"] if cf else None,
+        "peak": round(VALU_PEAK_GINST, 1),
+        "unit": "G wave-instructions/s",
+        "frac": cf["valu_frac"] if cf else None,
+        "traffic": cf["traffic_per_launch"] if cf else None,
+        "kernel": TRACE_KERNELS[walk],
+        "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+        "launches": launches,
+        "launches_overlap": overlap,
+        "counters": cf,
+        "hbm": {
+            "bound": "hbm", "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(hbm_achieved / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_ray": round(alg_bytes / max(rays, 1), 1),
+            "algorithmic_bytes_per_launch": round(bytes_per_launch),
+            "note": "algorithmic bytes of the traversal launches / their HIP-event duration; the bytes are served from "
+                    "cache (counters.hbm_frac is what reaches HBM), so this is not the binding roof",
+            "serial": serial,
+        },
+    }
+    if flops is not None and ms_trav > 0:
+        r["fp64_valu_tflops"] = round(flops / (ms_trav / 1e3) / 1e12, 3)
+        r["fp64_valu_frac"] = round(flops / (ms_trav / 1e3) / 1e12 / FP64_PEAK_TFLOPS, 4)
+    return r
+
+
+def work_flops(st):
+    return (45 * st.branch_visits + 33 * (st.aabb_tests + st.content_tests) + 17 * st.content_tests
+            + 45 * st.triangle_tests + 50 * st.hits_accepted)
 
 
 def main():
@@ -52,28 +163,36 @@ def main():
                          "its two half-frame chunks on the library's two streams)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--mesh", default="backpack", help="reference model fixture (backpack, teapot) or 'procedural'")
+    ap.add_argument("--repeats", type=int, default=5, help="further timed regions of --steps frames for the spread (the "
+                                                           "first region is the reported one)")
+    ap.add_argument("--frames16", type=int, default=10, help="frames timed per 16-spp workload")
+    ap.add_argument("--only", choices=["all", "main", "f16w", "f16p"], default="all",
+                    help="run one workload only (profiling runs)")
+    ap.add_argument("--pmc-run", action="store_true",
+                    help="profiling run: only the warm-up and timed frames are rendered (no counting pass, serial leg, "
+                         "repeats or CPU baseline), so every launch the profiler sees belongs to one of warmup + steps "
+                         "(or 1 + frames16) frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-frame16", action="store_true", help="skip the 16-spp soft-shadow frame timing")
+    ap.add_argument("--no-frame16", action="store_true", help="skip the 16-spp frames")
     ap.add_argument("--serial-chunks", action="store_true",
                     help="render a frame's two half-frame chunks one after the other instead of on two streams: "
                          "launches then run alone, which is how the per-launch figures of the roofline are best read")
-    ap.add_argument("--store-camera-rays", action="store_true",
-                    help="write the camera rays with a generate kernel and read them back (RTX_FLAG_STORE_CAMERA_RAYS) "
-                         "instead of computing them in the kernels of level 0; same image, for comparison")
-    ap.add_argument("--accumulate-samples", action="store_true",
-                    help="clear the sample slots, add every term and resolve (RTX_FLAG_ACCUMULATE_SAMPLES) instead of "
-                         "storing finished samples; same image, for comparison")
-    ap.add_argument("--store-light-rays", action="store_true",
-                    help="store every light ray's direction and light distance (RTX_FLAG_STORE_LIGHT_RAYS) instead of "
-                         "recomputing them from the origin; same image, for comparison")
+    ap.add_argument("--store-camera-rays", action="store_true", help="RTX_FLAG_STORE_CAMERA_RAYS; same image, for comparison")
+    ap.add_argument("--accumulate-samples", action="store_true", help="RTX_FLAG_ACCUMULATE_SAMPLES; same image, for comparison")
+    ap.add_argument("--store-light-rays", action="store_true", help="RTX_FLAG_STORE_LIGHT_RAYS; same image, for comparison")
     ap.add_argument("--no-serial-leg", action="store_true",
-                    help="skip the untimed repeat of the frames with chunks one after the other (roofline.serial)")
+                    help="skip the untimed repeat of the frames with chunks one after the other (roofline.hbm.serial)")
     ap.add_argument("--walk", choices=["bvh", "kd-culled", "reference"], default="bvh",
                     help="bvh: candidates from the library's BVH, verified against the reference's KD walk "
                          "(default render path); kd-culled: the reference's KD tree walked with culling; "
                          "reference: node for node as the reference's traverseKDTree.  All three give "
                          "identical images.")
     args = ap.parse_args()
+    if args.pmc_run:
+        args.no_cpu_baseline = True
+        args.no_serial_leg = True
+        args.repeats = 0
 
     import torch
     import torch.distributed as dist
@@ -100,9 +219,42 @@ def main():
             dist.init_process_group(backend)
     device.init(dev_index)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
+    counters = load_counters()
+    ctx = dict(args=args, rank=rank, world=world, dev=dev, comm_dev=comm_dev, backend=backend, counters=counters)
 
+    out = None
+    if args.only in ("all", "main"):
+        out = main_workload(ctx)
+    elif rank == 0:
+        out = {"metric": "Mrays/s (primary+secondary+shadow closest-hit queries)", "only": args.only}
+    if not args.no_frame16 and args.only != "main":
+        f16 = {}
+        if args.only in ("all", "f16w"):
+            f16["whitted_area_light"] = frame_16spp(ctx, "whitted")
+        if args.only in ("all", "f16p"):
+            f16["path_ggx"] = frame_16spp(ctx, "path")
+        if rank == 0:
+            out["frame_16spp"] = f16
+            if world > 1:
+                # the scaling figure of the 16-spp metric: one frame over all ranks (strong scaling);
+                # `value` above is frames of a sequence dealt out to the ranks (weak scaling)
+                out["strong_scaling"] = {k: {"ms_per_frame": v["ms_per_frame"], "Mrays_per_s": v["Mrays_per_s"], "n_gpus": world}
+                                         for k, v in f16.items()}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_workload(ctx):
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import abi, device, scenes
+    args, rank, world, dev, comm_dev, backend = (ctx[k] for k in ("args", "rank", "world", "dev", "comm_dev", "backend"))
     W, H = args.width, args.height
-    scene, _ = scenes.mesh_scene()
+    mesh = None if args.mesh == "procedural" else args.mesh
+    scene, _ = scenes.mesh_scene(mesh=mesh)
     desc = scene.frame(0.0)
     kd = scene.kd_stats()
     kflags = {"bvh": 0, "kd-culled": abi.FLAG_KD_CULLED, "reference": abi.FLAG_REFERENCE_ORDER}[args.walk]
@@ -158,14 +310,12 @@ def main():
                 pending[k] = None
 
     # ---- algorithmic bytes of exactly the timed frames (untimed, counting kernels) ----
-    alg_bytes = 0
-    work = {k: 0 for k in ("branch_visits", "leaf_visits", "aabb_tests", "triangle_tests", "sphere_tests", "hits_accepted",
-                           "content_tests")}
-    for s in range(args.steps):
-        st = ds.render_device(rd_for(args.warmup + s, abi.FLAG_COUNTERS), fb.data_ptr())
-        alg_bytes += abi.algorithmic_bytes(st, args.walk)
-        for k in work:
-            work[k] += getattr(st, k)
+    alg_bytes, flops = 0, 0
+    if not args.pmc_run:
+        for s in range(args.steps):
+            st = ds.render_device(rd_for(args.warmup + s, abi.FLAG_COUNTERS), fb.data_ptr())
+            alg_bytes += abi.algorithmic_bytes(st, args.walk)
+            flops += work_flops(st)
 
     # The frames of the sequence are queued without the host waiting in between (the buffers stay
     # on the device and the stream orders render -> present -> gather); one wait ends the region.
@@ -182,18 +332,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sync()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        step_fn(args.warmup + s, abi.FLAG_TRACE_TIMES)      # HIP events around the traversal launches only
-    queued_s = time.perf_counter() - t0                     # host time to queue the steps
-    drain()
-    totals = [h.wait() for h in handles]        # statistics summed over each handle's frames
-    sync()
-    elapsed = time.perf_counter() - t0
+    def timed_region(first_step):
+        sync()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            step_fn(first_step + s, abi.FLAG_TRACE_TIMES)      # HIP events around the traversal launches only
+        queued = time.perf_counter() - t0                       # host time to queue the steps
+        drain()
+        totals = [h.wait() for h in handles]                    # statistics summed over each handle's frames
+        sync()
+        return time.perf_counter() - t0, queued, totals
+
+    elapsed, queued_s, totals = timed_region(args.warmup)
     rays = sum(st.rays for st in totals)
     launches = sum(st.traverse_launches for st in totals)
     ms_trav = sum(st.ms_traverse + st.ms_shadow for st in totals)
+    # the same K frames again, several times: the spread of the timed region
+    spread = []
+    for _ in range(max(0, args.repeats)):
+        e, _, _ = timed_region(args.warmup)
+        spread.append(e)
     for h in handles:
         h.set_async(False)
 
@@ -211,31 +369,27 @@ def main():
             serial = {"achieved": round(s_achieved, 2), "frac": round(s_achieved / HBM_PEAK_GBS, 4),
                       "avg_launch_ms": round(s_ms / s_launches, 4), "launches": s_launches}
 
-    tt = torch.tensor([elapsed, float(rays), ms_trav, float(launches), float(alg_bytes)], dtype=torch.float64, device=comm_dev)
+    tt = torch.tensor([elapsed, float(rays)] + spread, dtype=torch.float64, device=comm_dev)
     if world > 1:
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         elapsed = mx[0].item()
+        spread = [mx[2 + k].item() for k in range(len(spread))]
         total_rays = tt[1].item()
     else:
         total_rays = float(rays)
 
+    out = None
     if rank == 0:
         frames = args.steps * world
         value = total_rays / elapsed / 1e6
-        avg_launch_s = (ms_trav / 1e3) / max(launches, 1)
-        bytes_per_launch = alg_bytes / max(launches, 1)
-        achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        flops = (45 * work["branch_visits"] + 33 * (work["aabb_tests"] + work["content_tests"]) + 17 * work["content_tests"]
-                 + 45 * work["triangle_tests"] + 50 * work["hits_accepted"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.walk == "bvh" and (kflags & abi.FLAG_SERIAL_CHUNKS):    # measured for that walk, per whole-frame launch
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        ms_per_step = elapsed / args.steps * 1e3
+        regions = sorted([elapsed] + spread)
+        cf = counter_figures(ctx["counters"], "main", args.walk, ms_per_step / world, ("k_trace_pool<false",))
+        mesh_name = ("reference model 'backpack' (Raytracer/Models/backpack/backpack.fbx through the library's FBX reader; "
+                     "fixture tests/golden/mesh_backpack.npz), 67908 triangles + 2 floor triangles") if mesh == "backpack" else \
+            (f"reference model '{mesh}' + 2 floor triangles" if mesh else "seeded bumpy UV sphere, 60024 triangles + 2 floor triangles")
         out = {
             "metric": "Mrays/s (primary+secondary+shadow closest-hit queries)",
             "value": round(value, 3),
@@ -243,15 +397,15 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: triangle mesh through KDTree, primary + hard shadow rays, 1080p 1spp",
-                "mesh": "seeded bumpy UV sphere, 60024 triangles + 2 floor triangles",
+                "workload": "configs[1]: triangle mesh from Raytracer/Models through KDTree, primary + hard shadow rays, 1080p 1spp",
+                "mesh": mesh_name,
                 "kd_tree": kd, "resolution": [W, H], "spp": 1, "light": "DirectionalLight(-1,-1,-1)",
                 "integrator": "whitted", "frames_per_step": world, "walk": args.walk,
                 "parallelism": (f"frames x{world}, {'RCCL' if backend == 'nccl' else backend} gather of the presented "
@@ -262,67 +416,72 @@ def main():
             "rays_per_frame": total_rays / frames,
             "ms_per_frame": round(elapsed / frames * 1e3, 4),       # sequence throughput: all ranks' frames
             "host_ms_per_step": round(queued_s / args.steps * 1e3, 4),   # rank 0's host time to queue one step
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": {"bvh": "k_trace_pool<false,3> (primary) and <false,4> (shadow): BVH candidates + KD membership verification",
-                           "kd-culled": "k_trace_pool<false,1> (primary) and <false,2> (shadow): culled walk of the reference's KD tree",
-                           "reference": "k_trace_pool<false,0>: the reference's KD walk, node for node"}[args.walk],
-                "algorithmic_bytes_per_ray": round(alg_bytes / max(rays, 1), 1),
-                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
-                # two half-frame chunks run on two streams: a launch shares the machine with the other
-                # chunk's kernels, so its duration (and `achieved`) is that of a kernel on part of the GPU
-                "launches_overlap": F > 1 or not args.serial_chunks,
-                "serial": serial,
-                "fp64_valu_tflops": round(flops / (ms_trav / 1e3) / 1e12, 3) if ms_trav > 0 else None,
-                "fp64_valu_frac": round(flops / (ms_trav / 1e3) / 1e12 / FP64_PEAK_TFLOPS, 4) if ms_trav > 0 else None,
-            },
+            # the timed region repeated on the same frames: `value` is the first region's
+            "timed_region_ms": {"reported": round(elapsed * 1e3, 3), "repeats": len(regions),
+                                "min": round(regions[0] * 1e3, 3), "median": round(regions[len(regions) // 2] * 1e3, 3),
+                                "max": round(regions[-1] * 1e3, 3)},
+            "roofline": roofline_block(args.walk, alg_bytes, rays, ms_trav, launches, ms_per_step / world, cf, serial=serial,
+                                       overlap=F > 1 or not args.serial_chunks, flops=flops),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(desc, lambda f: rd_for(f, 0), args.warmup)
+            out["cpu_baseline"] = cpu_baseline_frames(desc, lambda f: rd_for(f, 0), args.warmup)
     for h in handles[1:]:
         h.close()
     ds.close()
-    if not args.no_frame16:
-        # second half of the headline metric: ms per 1080p 16-spp frame, one frame split into
-        # interleaved row bands over all ranks (strong scaling), bands gathered on rank 0
-        f16 = frame_16spp(world, rank, dev, comm_dev, stream, W, H)
-        if rank == 0:
-            out["frame_16spp"] = f16
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
 
 
-def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
-    """BASELINE.json configs[3]: the mesh with GGX material parameters, albedo texture, checker
-    floor and a 1x1 SquareLight (2x2 light samples per hit), Whitted integrator, 4x4 sub-samples."""
+def frame_16spp(ctx, kind):
+    """BASELINE.json configs[3] at 1920x1080, 4x4 sub-samples per pixel.
+    kind 'whitted': rayTrace; the mesh with GGX material parameters and an albedo texture, checker
+    floor, one 1x1 SquareLight sampled 2x2 per hit (soft shadows).
+    kind 'path': pathTrace, depth 8; the same mesh and floor, CookTorance / GGX Gp on every bounce, lit
+    by an emissive sphere where the square light was (pathTrace knows no Light objects)."""
     import torch
     import torch.distributed as dist
     from raytracer_amd import abi, device, scenes
     from raytracer_amd import dist as rdist
-    scene, _ = scenes.mesh_scene(ggx=True, square_light=True)
+    args, rank, world, dev, comm_dev = (ctx[k] for k in ("args", "rank", "world", "dev", "comm_dev"))
+    W, H = args.width, args.height
+    frames = max(1, args.frames16)
+    mesh = None if args.mesh == "procedural" else args.mesh
+    scene, _ = scenes.mesh_scene(ggx=True, square_light=True, mesh=mesh)
+    if kind == "path":
+        scene.sphere((0.0, 10.0, 0.0), 2.0, scene.material("PlainWhiteTees", emission=(8.0, 8.0, 8.0)))
     desc = scene.frame(0.0)
+    stream = torch.cuda.current_stream().cuda_stream
     ds = device.DeviceScene(desc, stream=stream)
-    # Every rank renders its share of the frame -- the groups of 8 rows g with g % world == rank,
-    # one tile of interleaved rows (tile_row_group / tile_row_stride) -- in ONE call, whose two
-    # chunks run on the library's two streams.  The mesh fills the middle rows and the slowest
-    # rank's share sets the frame time: groups of 8 rows balance the ranks to within a row group
-    # without cutting the work into many short launches.  (One rank's share of an 8-rank frame,
-    # timed on one GPU: 3.35 ms as 4 bands of rows, 2.78 ms as 12 bands, 2.62 ms this way;
-    # 19.1 / 8 = 2.39 ms.)
-    rays = [0]
+    kflags = {"bvh": 0, "kd-culled": abi.FLAG_KD_CULLED, "reference": abi.FLAG_REFERENCE_ORDER}[args.walk]
 
-    def one_frame(f):
+    def rd_for(f, flags=0, tile=None, group=0, stride=0):
         cam = scenes.orbit_camera(f / 30.0)
+        if kind == "whitted":
+            return scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=4, light_n=2, max_depth=3,
+                                      bias=1e-2, frame=f, tile=tile, row_group=group, row_stride=stride, flags=flags | kflags)
+        return scenes.render_desc(W, H, integrator=abi.INTEGRATOR_PATH, camera=cam, n=4, max_depth=8, bias=1e-3, frame=f,
+                                  tile=tile, row_group=group, row_stride=stride, flags=flags | kflags)
 
+    # Every rank renders its share of the frame -- the groups of 8 rows g with g % world == rank, one
+    # tile of interleaved rows -- in ONE call (overwriting: no fill), presents its rows (8-bit sRGB)
+    # and rank 0 gathers those and places them with one strided copy.
+    acc = {"rays": 0, "ms_trav": 0.0, "launches": 0}
+    shown_rows = {}
+
+    def one_frame(f, flags):
         def render_rows(y0, rows, group, stride, out):
-            rd = scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=4, light_n=2, max_depth=3,
-                                    bias=1e-2, frame=f, tile=(0, y0, W, rows), row_group=group, row_stride=stride)
-            rays[0] += ds.render_device(rd, out.data_ptr()).rays
-        return rdist.render_frame_rows(render_rows, W, H, dev, group=8,
+            st = ds.render_device(rd_for(f, flags | abi.FLAG_OVERWRITE, (0, y0, W, rows), group, stride), out.data_ptr())
+            acc["rays"] += st.rays
+            acc["ms_trav"] += st.ms_traverse + st.ms_shadow
+            acc["launches"] += st.traverse_launches
+
+        def finish(rows_f32):
+            n = rows_f32.shape[0]
+            if n not in shown_rows:
+                shown_rows[n] = torch.zeros((n, W, 3), dtype=torch.uint8, device=dev)
+            ds.present_device(rows_f32.data_ptr(), W, n, shown_rows[n].data_ptr(), passes=1,
+                              tonemap=abi.TONEMAP_CBRT if kind == "path" else abi.TONEMAP_NONE, flip=False)
+            return shown_rows[n]
+        return rdist.render_frame_rows(render_rows, W, H, dev, group=8, finish=finish, zero=False,
                                        comm_device=None if comm_dev == dev else comm_dev)
 
     def sync():
@@ -330,37 +489,75 @@ def frame_16spp(world, rank, dev, comm_dev, stream, W, H, frames=3):
             dist.barrier()
         torch.cuda.synchronize()
 
-    one_frame(0)
-    rays[0] = 0
+    # algorithmic bytes: one counted frame (the first timed one), untimed
+    alg_bytes_frame, flops_frame, rays_frame = 0, 0, 0
+    if not args.pmc_run:
+        y0, rows, stride = rdist.rank_rows(H, world, rank, 8)
+        scratch = torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev)
+        st = ds.render_device(rd_for(1, abi.FLAG_COUNTERS, (0, y0, W, rows), 8, stride), scratch.data_ptr())
+        alg_bytes_frame, flops_frame, rays_frame = abi.algorithmic_bytes(st, args.walk), work_flops(st), st.rays
+        del scratch
+    one_frame(0, abi.FLAG_TRACE_TIMES)
+    acc.update(rays=0, ms_trav=0.0, launches=0)
     sync()
+    per_frame = []
     t0 = time.perf_counter()
     for f in range(1, frames + 1):
-        one_frame(f)
+        t1 = time.perf_counter()
+        one_frame(f, abi.FLAG_TRACE_TIMES)
+        per_frame.append(time.perf_counter() - t1)
     sync()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt, float(rays[0])], dtype=torch.float64, device=comm_dev)
+    tt = torch.tensor([dt, float(acc["rays"])], dtype=torch.float64, device=comm_dev)
     if world > 1:
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt = mx[0].item()
+    total_rays = tt[1].item()
+    out = None
+    if rank == 0:
+        ms_per_frame = dt / frames * 1e3
+        per_frame.sort()
+        wl = "f16w" if kind == "whitted" else "f16p"
+        dominant = ("k_trace_pool<false, 4>",) if kind == "whitted" else ("k_trace_pool<false, 3>",)
+        cf = counter_figures(ctx["counters"], wl, args.walk, ms_per_frame, dominant) if world == 1 else None
+        # the counted frame stands for the timed ones (the camera moves 1/30 s per frame)
+        scale = (acc["rays"] / rays_frame) if rays_frame else 0.0
+        out = {
+            "workload": ("configs[3] (rayTrace): GGX-parameter mesh, albedo texture + checker floor, SquareLight 1x1 sampled "
+                         "2x2 per hit, 1080p 16 spp" if kind == "whitted" else
+                         "configs[3] (pathTrace): the same mesh and floor, CookTorance/GGX Gp bounces, depth 8, lit by an "
+                         "emissive sphere, 1080p 16 spp"),
+            "mesh": args.mesh, "integrator": kind,
+            "ms_per_frame": round(ms_per_frame, 3),
+            "ms_per_frame_min_median": [round(per_frame[0] * 1e3, 3), round(per_frame[len(per_frame) // 2] * 1e3, 3)],
+            "Mrays_per_s": round(total_rays / dt / 1e6, 1),
+            "rays_per_frame": round(total_rays / frames),
+            "frames": frames, "n_gpus": world, "scaling": "strong",
+            "step": ("every rank renders its interleaved groups of 8 rows (group g to rank g % N) as one tile in one call, "
+                     "presents them (8-bit sRGB) and rank 0 gathers the presented rows" if world > 1 else
+                     "render (float framebuffer in HBM) + present (8-bit sRGB); one frame at a time, its two half-frame chunks "
+                     "on the library's two streams"),
+            "roofline": roofline_block(args.walk, alg_bytes_frame * scale, acc["rays"], acc["ms_trav"], acc["launches"],
+                                       ms_per_frame, cf, overlap=True, flops=flops_frame * scale),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_rows(desc, lambda tile: rd_for(1, 0, tile), W, H)
     ds.close()
-    return {"workload": "configs[3]: GGX-parameter mesh, texture + checker floor, SquareLight 2x2 samples, 1080p 16 spp, "
-                        f"whitted; every rank renders its interleaved groups of 8 rows (group g to rank g % {world}) as one "
-                        "tile in one call, float rows gathered on rank 0",
-            "ms_per_frame": round(dt / frames * 1e3, 3), "Mrays_per_s": round(tt[1].item() / dt / 1e6, 1),
-            "frames": frames, "n_gpus": world, "scaling": "strong"}
+    return out
 
 
-def cpu_baseline(desc, rd_of_frame, first_frame, budget_s=12.0, max_frames=40):
+def cpu_baseline_frames(desc, rd_of_frame, first_frame, budget_s=10.0, max_frames=40):
     """The CPU oracle (a port of the reference's loop, OpenMP over pixels in place of
     concurrency::parallel_for) on a bounded sample of the same workload: whole frames of the
     timed sequence, starting with the first timed one, until about `budget_s` seconds of CPU
-    work have been spent."""
+    work have been spent.  The CPU walks the reference's KD tree in the reference's order (the GPU
+    finds the same hits through its own BVH): same rays, same answers, not the same work.
+    `reference_costs` repeats a part of the sample with the overheads the reference itself has
+    (leaf vectors copied per visit, sphere matrices per test / hit)."""
     from oracle import binding as orc
-    rays = 0
-    frames = 0
-    threads = 1
+    rays, frames, threads = 0, 0, 1
     t0 = time.perf_counter()
     while frames < max_frames:
         _, _, st, threads = orc.render(desc, rd_of_frame(first_frame + frames))
@@ -369,9 +566,60 @@ def cpu_baseline(desc, rd_of_frame, first_frame, budget_s=12.0, max_frames=40):
         if time.perf_counter() - t0 >= budget_s:
             break
     dt = time.perf_counter() - t0
+    orc.set_reference_costs(True)
+    try:
+        t1 = time.perf_counter()
+        rc_rays, rc_frames = 0, 0
+        while rc_frames < max(1, frames // 3):
+            _, _, st, _ = orc.render(desc, rd_of_frame(first_frame + rc_frames))
+            rc_rays += st.rays
+            rc_frames += 1
+        rc_dt = time.perf_counter() - t1
+    finally:
+        orc.set_reference_costs(False)
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{frames} whole 1080p frames of the timed sequence from frame {first_frame} on "
-                      f"({rays} rays, {dt:.1f} s; OpenMP schedule(dynamic,64), gcc -O2 -ffp-contract=off)"}
+                      f"({rays} rays, {dt:.1f} s; OpenMP schedule(dynamic,64), gcc -O2 -ffp-contract=off)",
+            "walk": "the reference's KD tree in the reference's visit order (KDTree.cpp:158-220)",
+            "reference_costs": {"value": round(rc_rays / rc_dt / 1e6, 4), "unit": "Mrays/s",
+                                "sample": f"{rc_frames} of those frames with the leaf vector copied per visit (KDTree.cpp:206) "
+                                          f"and the sphere matrix work per test and hit (Sphere.cpp:47-48,74) ({rc_dt:.1f} s)"}}
+
+
+def cpu_baseline_rows(desc, rd_of_tile, W, H, budget_s=8.0, band=4):
+    """The CPU oracle on bands of rows of one 16-spp frame (the first timed one), alternating
+    outwards from the middle of the picture (where the mesh is) until about `budget_s` seconds
+    have been spent; then one band again with the reference's own overheads."""
+    from oracle import binding as orc
+    rays, rows, threads = 0, 0, 1
+    mid = H // 2
+    order = [mid]
+    for j in range(1, H // band):
+        order += [y for y in (mid + j * band, mid - j * band) if 0 <= y and y + band <= H]
+    t0 = time.perf_counter()
+    used = []
+    for y in order:
+        _, _, st, threads = orc.render(desc, rd_of_tile((0, y, W, band)))
+        rays += st.rays
+        rows += band
+        used.append(y)
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    dt = time.perf_counter() - t0
+    orc.set_reference_costs(True)
+    try:
+        t1 = time.perf_counter()
+        _, _, st, _ = orc.render(desc, rd_of_tile((0, used[0], W, band)))
+        rc = st.rays / (time.perf_counter() - t1) / 1e6
+    finally:
+        orc.set_reference_costs(False)
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "ms_per_frame_extrapolated": round(dt / rows * H * 1e3, 1),
+            "sample": f"{rows} of {H} rows of the first timed frame, bands of {band} rows outwards from the middle row "
+                      f"({min(used)}..{max(used) + band - 1}; {rays} rays, {dt:.1f} s; OpenMP schedule(dynamic,64), gcc -O2 "
+                      "-ffp-contract=off)",
+            "walk": "the reference's KD tree in the reference's visit order (KDTree.cpp:158-220)",
+            "reference_costs": {"value": round(rc, 4), "unit": "Mrays/s", "sample": f"the middle band of {band} rows again"}}
 
 
 if __name__ == "__main__":

@@ -108,6 +108,12 @@ def render(desc, rd, accum=None, threads=0, want_rgb64=False):
     return accum, rgb64, stats, used.value
 
 
+def set_reference_costs(on):
+    """orc_set_reference_costs: the render / trace calls repeat the work the reference repeats
+    (leaf vector copies, per-test and per-hit sphere matrix work); same results, slower."""
+    lib().orc_set_reference_costs(int(bool(on)))
+
+
 def camera_rays(rd, sub_sample=None):
     """Origins/directions of the camera rays of rd's tile (one per pixel; sub_sample=(sx,sy), default (1,1))."""
     L = lib()

@@ -210,12 +210,57 @@ void orc_solve_quadratic(double a, double b, double c, double* A1, double* A2)
     *A2 = (-b - sqrt(disc)) / (2.0 * a);
 }
 
+/* Reference-cost mode (orc_set_reference_costs): the restatement above hoists work the reference
+ * repeats -- it copies the leaf's std::vector<Shape*> by value on every leaf visit
+ * (rayHitListOfShapes takes it by value, KDTree.cpp:206), evaluates getModel(t) and
+ * transformPos per sphere test (Sphere.cpp:47-48) and inverts the 4x4 model matrix per accepted
+ * sphere hit (transformNormal, Sphere.cpp:74, CoordinateHelpers.cpp:12-16).  With the mode on, the
+ * same work is done again (its results discarded: they equal the hoisted ones), so that a CPU
+ * baseline timed this way is not flattered by the clean-ups.  Results are unchanged. */
+static int g_reference_costs = 0;
+void orc_set_reference_costs(int on) { g_reference_costs = on; }
+static volatile double g_cost_sink;
+
+static void cost_mat4_times_point(const double* m, v3 p)
+{
+    double o[4];
+    for (int i = 0; i < 4; ++i) o[i] = (m[0 + i] * p.x + m[4 + i] * p.y) + (m[8 + i] * p.z + m[12 + i] * 1.0);
+    g_cost_sink = o[0] / o[3] + o[1] / o[3] + o[2] / o[3];
+}
+
+/* glm::inverse(mat4): cofactor expansion (what transformNormal runs per hit) */
+static void cost_mat4_inverse(const double* m)
+{
+    double c00 = m[10] * m[15] - m[14] * m[11], c02 = m[6] * m[15] - m[14] * m[7], c03 = m[6] * m[11] - m[10] * m[7];
+    double c04 = m[9] * m[15] - m[13] * m[11], c06 = m[5] * m[15] - m[13] * m[7], c07 = m[5] * m[11] - m[9] * m[7];
+    double c08 = m[9] * m[14] - m[13] * m[10], c10 = m[5] * m[14] - m[13] * m[6], c11 = m[5] * m[10] - m[9] * m[6];
+    double c12 = m[8] * m[15] - m[12] * m[11], c14 = m[4] * m[15] - m[12] * m[7], c15 = m[4] * m[11] - m[8] * m[7];
+    double c16 = m[8] * m[14] - m[12] * m[10], c18 = m[4] * m[14] - m[12] * m[6], c19 = m[4] * m[10] - m[8] * m[6];
+    double c20 = m[8] * m[13] - m[12] * m[9], c22 = m[4] * m[13] - m[12] * m[5], c23 = m[4] * m[9] - m[8] * m[5];
+    double f0[4] = {c00, c00, c02, c03}, f1[4] = {c04, c04, c06, c07}, f2[4] = {c08, c08, c10, c11};
+    double f3[4] = {c12, c12, c14, c15}, f4[4] = {c16, c16, c18, c19}, f5[4] = {c20, c20, c22, c23};
+    double v0[4] = {m[4], m[0], m[0], m[0]}, v1[4] = {m[5], m[1], m[1], m[1]};
+    double v2[4] = {m[6], m[2], m[2], m[2]}, v3_[4] = {m[7], m[3], m[3], m[3]};
+    double inv[16], sign = 1.0;
+    for (int k = 0; k < 4; ++k, sign = -sign) {
+        inv[0 + k] = sign * ((v1[k] * f0[k] - v2[k] * f1[k]) + v3_[k] * f2[k]);
+        inv[4 + k] = -sign * ((v0[k] * f0[k] - v2[k] * f3[k]) + v3_[k] * f4[k]);
+        inv[8 + k] = sign * ((v0[k] * f1[k] - v1[k] * f3[k]) + v3_[k] * f5[k]);
+        inv[12 + k] = -sign * ((v0[k] * f2[k] - v1[k] * f4[k]) + v2[k] * f5[k]);
+    }
+    double det = (m[0] * inv[0] + m[1] * inv[4]) + (m[2] * inv[8] + m[3] * inv[12]);
+    double one_over = 1.0 / det, acc = 0.0;
+    for (int k = 0; k < 16; ++k) acc += inv[k] * one_over;
+    g_cost_sink = acc;
+}
+
 /* Sphere::rayHit, Sphere.cpp:41-81, with transOrigin = transformPos(origin, model)
  * and normalMat = inverse(transpose(model)) (CoordinateHelpers.cpp:12-20) evaluated
  * once per frame by the host */
 static int sphere_hit(const double* center, double r2, const double* nm, const ray_t* r, hit_t* h)
 {
     v3 c0 = ld3(center);
+    if (g_reference_costs) cost_mat4_times_point(nm, c0);       /* getModel + transformPos per test */
     v3 L = sub(r->origin, c0);
     double a = dot(r->direction, r->direction);
     double b = 2.0 * dot(r->direction, L);
@@ -227,6 +272,7 @@ static int sphere_hit(const double* center, double r2, const double* nm, const r
     if (t0 < 0) { t0 = t1; if (t0 < 0) return 0; }
     h->position = add(r->origin, muls(r->direction, t0));
     v3 n = normalize3(sub(h->position, c0));
+    if (g_reference_costs) cost_mat4_inverse(nm);               /* inverse(transpose(model)) per hit */
     /* normalMat * dvec4(n, 1.0), truncated to xyz */
     double o[3];
     for (int i = 0; i < 3; ++i) {
@@ -318,6 +364,19 @@ static void traverse(const rtx_scene_desc* s, int32_t node, const ray_t* r, hit_
             ctx->leaf_hash *= 1099511628211ull;
         }
         ctx->leaf++;
+        if (g_reference_costs) {
+            /* the by-value std::vector<Shape*> argument: allocate, copy 8-byte pointers, free */
+            uint32_t cnt = s->leaf_count[leaf];
+            const uint32_t* refs = s->leaf_refs + s->leaf_first[leaf];
+            uint64_t* copy = (uint64_t*)malloc((size_t)(cnt ? cnt : 1) * sizeof(uint64_t));
+            uint32_t* narrow = (uint32_t*)malloc((size_t)(cnt ? cnt : 1) * sizeof(uint32_t));
+            for (uint32_t k = 0; k < cnt; ++k) copy[k] = refs[k];
+            for (uint32_t k = 0; k < cnt; ++k) narrow[k] = (uint32_t)copy[k];
+            hit_list(s, narrow, cnt, r, best, ctx);
+            free(narrow);
+            free(copy);
+            return;
+        }
         hit_list(s, s->leaf_refs + s->leaf_first[leaf], s->leaf_count[leaf], r, best, ctx);
         return;
     }

@@ -68,6 +68,10 @@ int  orc_sphere_hit(const double center[3], double r2, const double nmat[16],
                     const double origin[3], const double dir[3], double position[3],
                     double normal[3], double uv[2], double* depth);
 void orc_solve_quadratic(double a, double b, double c, double* r1, double* r2);
+/* 1: repeat the work the reference repeats (leaf vector copied per visit, KDTree.cpp:206; model
+   matrix applied per sphere test and inverted per sphere hit, Sphere.cpp:47-48,74) so that a timed
+   CPU baseline carries the reference's own overheads.  Results are unchanged. */
+void orc_set_reference_costs(int on);
 int orc_entering_for_dot(double x);     /* acos(x) < pi/2.0, as Raytracer.cpp:248-249 evaluates it */
 void orc_refraction_ray(const double n[3], const double d[3], double ior, int entering,
                         double out[3], int* internal_only);

@@ -276,7 +276,9 @@ RTX_DEV bool sphere_t(d3 center, double r2, d3 o, d3 d, double& t)
     return true;
 }
 
-RTX_DEV bool sphere_full(const DScene& s, uint32_t sph, d3 o, d3 d, Hit& h)
+// need_uv = false leaves uv at 0: for callers that do not read it (no sampler of the hit's
+// material takes uv, or only position and normal are wanted), atan2 being the costliest part
+RTX_DEV bool sphere_full(const DScene& s, uint32_t sph, d3 o, d3 d, Hit& h, bool need_uv = true)
 {
     d3 c = ld3(s.sph_center + 3 * (size_t)sph);
     double t;
@@ -288,8 +290,8 @@ RTX_DEV bool sphere_full(const DScene& s, uint32_t sph, d3 o, d3 d, Hit& h)
     h.normal.x = (m[0] * n.x + m[4] * n.y) + (m[8] * n.z + m[12] * 1.0);
     h.normal.y = (m[1] * n.x + m[5] * n.y) + (m[9] * n.z + m[13] * 1.0);
     h.normal.z = (m[2] * n.x + m[6] * n.y) + (m[10] * n.z + m[14] * 1.0);
-    h.u = atan2(h.normal.x, h.normal.z) / (2 * kPi) + 0.5;
-    h.v = h.normal.y * 0.5 + 0.5;
+    h.u = need_uv ? atan2(h.normal.x, h.normal.z) / (2 * kPi) + 0.5 : 0.0;
+    h.v = need_uv ? h.normal.y * 0.5 + 0.5 : 0.0;
     h.bary = mk(0.0, 0.0, 0.0);
     h.depth = t;
     return true;
@@ -317,12 +319,18 @@ RTX_DEV bool biconvex_depth(const DScene& s, uint32_t lens, d3 o, d3 d, double& 
 }
 
 // full HitResult of primitive `prim` (a triangle or a sphere id, as reported by traversal)
-RTX_DEV bool prim_full(const DScene& s, uint32_t prim, d3 o, d3 d, Hit& h)
+RTX_DEV bool prim_full(const DScene& s, uint32_t prim, d3 o, d3 d, Hit& h, bool need_uv = true)
 {
     uint32_t info = s.prim_info[prim];
     h.prim = (int32_t)prim;
     if ((info & 3u) == RTX_PRIM_TRIANGLE) return triangle_full(s, info >> 2, o, d, h);
-    return sphere_full(s, info >> 2, o, d, h);
+    return sphere_full(s, info >> 2, o, d, h, need_uv);
+}
+
+// whether any channel of the material is read through a sampler, i.e. whether the hit's uv matters
+RTX_DEV bool material_reads_uv(const rtx_material& m)
+{
+    return (m.color_fn.kind | m.ns_fn.kind | m.ni_fn.kind | m.transparency_fn.kind | m.metalness_fn.kind | m.smoothness_fn.kind) != 0u;
 }
 
 // ---- materials (Material.cpp:111-161, Procedural.cpp:4-25, Texture.cpp:39-64) -------------
@@ -509,7 +517,10 @@ RTX_DEV d3 cook_torrance(d3 vi, d3 vo, d3 vn, double smooth, d3 down, d3 F0, d3&
     double ndi = dot(vn, vi);
     double cosT = dot(vo, vn);
     double sinT = sqrt(1 - cosT * cosT);
-    double p = pow(1.0 - dot(vh, vi), 5.0);
+    // pow(b, 5.0) (CookTorrance.cpp:41) as four multiplications: within 2 units in the last place
+    // of the exact power, the same order as the device pow's own distance from the C library's
+    const double b1 = 1.0 - dot(vh, vi), b2 = b1 * b1;
+    double p = (b2 * b2) * b1;
     d3 fres = F0 + (mk(1.0 - F0.x, 1.0 - F0.y, 1.0 - F0.z) * p);
     double geo = gp(vi, vn, vh, rough) * gp(vo, vn, vh, rough);
     double denom = 4.0 * (ndi * dot(vh, vn) + 0.05);

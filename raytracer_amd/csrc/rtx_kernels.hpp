@@ -1283,8 +1283,8 @@ k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* _
             d3 o = qr.o, d = qr.d;
             d3 inv_dir = -d;
             Hit h;
-            prim_full(s, (uint32_t)prim, o, d, h);
             const rtx_material& m = s.materials[s.prim_material[prim]];
+            prim_full(s, (uint32_t)prim, o, d, h, material_reads_uv(m));
             if (p.d.flags & RTX_FLAG_BASIC) {
                 sample_term(p, sample, slot, w * material_color(s, m, h.u, h.v));
             } else {
@@ -1382,7 +1382,7 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
         const Ray qr = queue_ray(p, q, i);
         d3 o = qr.o, d = qr.d;
         Hit h;
-        prim_full(s, (uint32_t)q.hit_prim[i], o, d, h);
+        prim_full(s, (uint32_t)q.hit_prim[i], o, d, h, false);      // position and normal only
         uint32_t slot = queue_slot(p, q, i);
         Rng rng = ray_rng(p, q, i, slot);
         d3 from = h.position + (h.normal * p.d.bias);
@@ -1442,8 +1442,8 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
         d3 o = qr.o, d = qr.d;
         d3 inv_dir = -d;
         Hit h;
-        prim_full(s, (uint32_t)q.hit_prim[i], o, d, h);
-        const rtx_material& m = s.materials[s.prim_material[h.prim]];
+        const rtx_material& m = s.materials[s.prim_material[q.hit_prim[i]]];
+        prim_full(s, (uint32_t)q.hit_prim[i], o, d, h, material_reads_uv(m));
         bool entering = is_entering(h.normal, inv_dir);
         d3 local;
         if (p.d.flags & RTX_FLAG_NO_LIGHTING) {

@@ -99,48 +99,63 @@ def rank_rows(height, world, rank, group=8):
     return rank * group, rows, world * group
 
 
-def render_frame_rows(render_rows, width, height, device, group=8, pg=None, comm_device=None, after=None):
+_buffers = {}
+
+
+def _buffer(tag, shape, dtype, device):
+    """A tensor kept between frames (no allocation, no fill per frame); contents are whatever
+    the last frame left."""
+    key = (tag, tuple(shape), dtype, str(device))
+    if key not in _buffers:
+        _buffers[key] = torch.zeros(shape, dtype=dtype, device=device)
+    return _buffers[key]
+
+
+def render_frame_rows(render_rows, width, height, device, group=8, pg=None, comm_device=None, after=None, finish=None,
+                      zero=True):
     """Render one frame cooperatively, every rank its interleaved groups of rows in ONE call.
 
-    render_rows(y0, rows, group, stride, out) must accumulate the float32 RGB of the tile
-    (0, y0, width, rows) with tile_row_group = group and tile_row_stride = stride into `out`
-    ([rows, width, 3] on `device`, zero-initialised here; packed rows).  Finer than bands and
-    without their many short launches: a rank's share is one tile of 1/world of the frame.
-    Returns the assembled [height, width, 3] frame on rank 0, None elsewhere.  `after()` is
-    called once the rank's work is queued and must make the current stream wait for it."""
+    render_rows(y0, rows, group, stride, out) renders the tile (0, y0, width, rows) with
+    tile_row_group = group and tile_row_stride = stride into `out` ([rows, width, 3] float32 on
+    `device`, packed rows).  With `zero` the buffer is cleared first (a render call adds to it);
+    a caller that renders with RTX_FLAG_OVERWRITE passes zero=False and saves the fill.  Finer than
+    bands and without their many short launches: a rank's share is one tile of 1/world of the frame.
+    `after()` is called once the rank's work is queued and must make the current stream wait for it.
+    `finish(rows_tensor)` may turn the rank's float rows into what is gathered instead -- e.g. the
+    presented 8-bit rows, a quarter of the bytes (a driver that accumulates passes keeps the float
+    rows on their rank and only ever needs the presented ones on rank 0).
+    Rank 0 returns the assembled [height, width, 3] frame (row 0 = bottom row, as the renderer
+    numbers them), the others None.  All buffers are kept between frames; rank 0 places the
+    gathered rows with ONE strided copy: rank r's k-th group is group r + k * world of the frame."""
     world = dist.get_world_size(pg) if dist.is_initialized() else 1
     rank = dist.get_rank(pg) if dist.is_initialized() else 0
-    most = max(rank_rows(height, world, r, group)[1] for r in range(world))
-    packed = torch.zeros((most, width, 3), dtype=torch.float32, device=device)
+    n_groups = (height + group - 1) // group
+    per_rank = (n_groups + world - 1) // world          # groups of the busiest rank
+    most = per_rank * group
+    packed = _buffer("packed", (most, width, 3), torch.float32, device)
     y0, rows, stride = rank_rows(height, world, rank, group)
     if rows:
+        if zero:
+            packed[:rows].zero_()
         render_rows(y0, rows, group, stride, packed[:rows])
     if after is not None:
         after()
-    if comm_device is not None and torch.device(comm_device) != packed.device:
-        packed = packed.to(comm_device)
-    parts = _gather_to_rank0(packed, world, rank, pg)
+    local = finish(packed) if finish is not None else packed
+    if comm_device is not None and torch.device(comm_device) != local.device:
+        local = local.to(comm_device)
+    if world == 1 and most == height:
+        return local                                     # one rank owns the rows in frame order
+    gathered = _buffer("gathered", (world, most, width, 3), local.dtype, local.device) if rank == 0 else None
+    if world == 1:
+        gathered[0].copy_(local)
+    else:
+        dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0, group=pg)
     if rank != 0:
         return None
-    frame = torch.empty((height, width, 3), dtype=torch.float32, device=packed.device)
-    for r in range(world):
-        rows = rank_rows(height, world, r, group)[1]
-        if rows:        # one scatter of whole rows per rank
-            frame.index_copy_(0, _frame_rows(height, world, r, group, packed.device), parts[r][:rows])
-    return frame
-
-
-_row_index_cache = {}
-
-
-def _frame_rows(height, world, rank, group, device):
-    """The frame rows of `rank`'s packed rows, as an index tensor on `device` (kept between frames)."""
-    key = (height, world, rank, group, str(device))
-    if key not in _row_index_cache:
-        y0, rows, stride = rank_rows(height, world, rank, group)
-        k = torch.arange(rows, dtype=torch.int64)
-        _row_index_cache[key] = (y0 + (k // group) * stride + k % group).to(device)
-    return _row_index_cache[key]
+    frame = _buffer("frame", (per_rank * world * group, width, 3), local.dtype, local.device)
+    # frame row (k * world + r) * group + j  <-  rank r, packed row k * group + j
+    frame.view(per_rank, world, group, width, 3).copy_(gathered.view(world, per_rank, group, width, 3).transpose(0, 1))
+    return frame[:height]
 
 
 def render_sequence_frames(render_frame, n_frames, width, height, device, group=None):

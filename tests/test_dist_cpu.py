@@ -65,6 +65,21 @@ def _worker(rank, world, port, mode, out_path):
         frame = rdist.render_frame_rows(render_rows, W, H, torch.device("cpu"), group=8)
         if rank == 0:
             np.save(out_path, frame.numpy())
+    elif mode == "rows-rgb8":
+        # every rank presents its own rows (8-bit sRGB, unflipped) and those are gathered; the
+        # render call overwrites, so the packed buffer is not cleared
+        def render_rows(y0, rows, group, stride, out):
+            rd = _rd(cam, tile=(0, y0, W, rows))
+            rd.tile_row_group, rd.tile_row_stride = group, stride
+            img, _, _, _ = orc.render(desc, rd, threads=2)
+            out.copy_(torch.from_numpy(img))
+
+        def finish(rows):
+            return torch.from_numpy(orc.present(rows.numpy(), passes=1, tonemap=1, flip=False))
+        for _ in range(2):              # the second frame reuses every buffer
+            frame = rdist.render_frame_rows(render_rows, W, H, torch.device("cpu"), group=8, finish=finish, zero=False)
+        if rank == 0:
+            np.save(out_path, frame.numpy())
     else:
         def render_frame(f, out):
             img, _, _, _ = orc.render(desc, _rd(cam, frame_t=f / 30.0), threads=2)
@@ -76,7 +91,7 @@ def _worker(rank, world, port, mode, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["bands", "even-bands", "rows", "frames"])
+@pytest.mark.parametrize("mode", ["bands", "even-bands", "rows", "rows-rgb8", "frames"])
 def test_two_ranks_reproduce_the_single_process_image(tmp_path, mode):
     out_path = str(tmp_path / "out.npy")
     mp.spawn(_worker, args=(2, _free_port(), mode, out_path), nprocs=2, join=True)
@@ -86,6 +101,9 @@ def test_two_ranks_reproduce_the_single_process_image(tmp_path, mode):
     if mode in ("bands", "even-bands", "rows"):
         want, _, _, _ = orc.render(desc, _rd(cam))
         assert np.array_equal(got, want)
+    elif mode == "rows-rgb8":
+        want, _, _, _ = orc.render(desc, _rd(cam))
+        assert got.dtype == np.uint8 and np.array_equal(got, orc.present(want, passes=1, tonemap=1, flip=False))
     else:
         for f in range(3):
             want, _, _, _ = orc.render(desc, _rd(cam, frame_t=f / 30.0))

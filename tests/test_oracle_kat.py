@@ -203,3 +203,31 @@ def test_mirror_direction_uses_sin_pi():
     ideal = d - 2.0 * d[1] * np.array([0.0, 1.0, 0.0])
     assert np.allclose(o, ideal, atol=1e-15)
     assert not np.array_equal(o, ideal)
+
+
+def test_entering_is_a_threshold_on_the_dot_product():
+    """`entering = acos(dot(n, -d)) < pi / 2.0` (Raytracer.cpp:248-249): pi / 2.0 is the double just
+    below the real pi/2, so the C library's acos compares below it exactly for
+    dot >= 1.7225464241988333e-16 (and <= 1: acos is NaN beyond).  The HIP code tests the dot
+    product against that constant instead of calling acos; here the oracle, which calls acos, is
+    swept over the bracket of the threshold and over the whole range."""
+    L = orc.lib()
+    L.orc_entering_for_dot.argtypes = [C.c_double]
+    T = np.array([0x3ca8d313198a2e04], dtype=np.uint64).view(np.float64)[0]
+    assert T == 1.7225464241988333e-16
+    text = open(os.path.join(os.path.dirname(__file__), "..", "raytracer_amd", "csrc", "rtx_device.hpp")).read()
+    assert "kEnteringMin = 1.7225464241988333e-16" in text
+
+    def expected(x):
+        return int(x >= T and x <= 1.0)
+
+    bits = np.uint64(0x3ca8d313198a2e04)
+    for k in range(-5000, 5001):
+        x = np.array([bits + np.uint64(k) if k >= 0 else bits - np.uint64(-k)], dtype=np.uint64).view(np.float64)[0]
+        assert L.orc_entering_for_dot(float(x)) == expected(x), (k, x)
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(-1.5, 1.5, 20000), 10.0 ** rng.uniform(-300, 0.2, 20000), -10.0 ** rng.uniform(-300, 0.2, 2000),
+                         [0.0, -0.0, 1.0, np.nextafter(1.0, 2.0), np.nextafter(1.0, 0.0), -1.0, np.nan, np.inf, -np.inf,
+                          5e-324, 2.2250738585072014e-308]])
+    for x in xs:
+        assert L.orc_entering_for_dot(float(x)) == expected(x), x

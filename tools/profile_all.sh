@@ -1,16 +1,19 @@
 #!/bin/bash
-# rocprofv3 kernel traces of bench.py for the three walks (four frames in flight, as in the timed
-# steps) and for the default walk with one frame at a time on one stream, then the counter passes
-# (run on the MI355X box from the repo root)
+# rocprofv3 kernel traces of bench.py (run on the MI355X box from the repo root): the headline
+# workload with four frames in flight (as in the timed steps) and with one frame at a time on one
+# stream, and each 16-spp frame on its own; then the counter passes (tools/profile_pmc.sh).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
-for walk in bvh kd-culled reference bvh-serial; do
-  steps=12; [ $walk = reference ] && steps=4
-  extra="--no-serial-leg --walk $walk"; [ $walk = bvh-serial ] && extra="--in-flight 1 --serial-chunks --walk bvh"
-  rm -rf $R/gpurun_out/kt_$walk
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_$walk -- python3 $R/bench.py --steps $steps --warmup 4 --no-cpu-baseline --no-frame16 $extra > $R/gpurun_out/kt_$walk.json 2> $R/gpurun_out/kt_$walk.err || exit 1
-  echo "kt $walk ok"
+for name in main main-serial f16w f16p; do
+  case $name in
+    main) extra="--only main --steps 12 --warmup 4 --no-cpu-baseline --no-serial-leg --repeats 0";;
+    main-serial) extra="--only main --steps 12 --warmup 4 --no-cpu-baseline --no-serial-leg --repeats 0 --in-flight 1 --serial-chunks";;
+    *) extra="--only $name --frames16 4 --no-cpu-baseline";;
+  esac
+  rm -rf $R/gpurun_out/kt_$name
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_$name -- python3 $R/bench.py $extra > $R/gpurun_out/kt_$name.json 2> $R/gpurun_out/kt_$name.err || exit 1
+  echo "kt $name ok"
 done
 cd $R && bash tools/profile_pmc.sh || exit 1
