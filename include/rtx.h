@@ -235,6 +235,10 @@ enum {
                                            material refracts) is stored once, and with one
                                            sub-sample per pixel written to the framebuffer at
                                            once.  Same image                                  */
+    RTX_FLAG_QUEUE_ORDER     = 1u << 18,/* the rays of the levels below the camera's are walked in queue
+                                           order.  Without it a level of 65 536 rays or more is walked in
+                                           the order of the rays' direction bins (neighbouring lanes then
+                                           follow similar paths; same hits, same image)            */
     RTX_FLAG_STORE_LIGHT_RAYS = 1u << 17  /* the first shading half stores every light ray's
                                            direction and light distance in the shadow queue.
                                            Without it, in a scene with one Point or Directional
@@ -393,7 +397,7 @@ int rtx_render_device(rtx_scene* scene, const rtx_render_desc* desc, float* accu
  * not wait: it returns once the work is queued on the scene's stream (synchronise that stream
  * before reading accum_device).  Same image, bit for bit, as rtx_render_device.
  * Limits: the tile is rendered as one chunk, so
- *     768 + 272 * S + 40 * S * L + 36 * S * G   (each array rounded up to 256 bytes)
+ *     768 + 272.2 * S + 40 * S * L + 36 * S * G   (each array rounded up to 256 bytes)
  * must not exceed RTX_NOALLOC_SCRATCH_BYTES, with S = tile_w * tile_h * n * n sample slots, L light
  * samples per hit (Whitted) and G gather rays per hit (GLOBAL_LIGHTING): e.g. 256 x 256 pixels at
  * 1 spp with four light samples, or 128 x 96 at 4 spp path traced.  Larger tiles get

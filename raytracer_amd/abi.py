@@ -43,6 +43,7 @@ FLAG_OVERWRITE = 1 << 14
 FLAG_STORE_CAMERA_RAYS = 1 << 15
 FLAG_ACCUMULATE_SAMPLES = 1 << 16
 FLAG_STORE_LIGHT_RAYS = 1 << 17
+FLAG_QUEUE_ORDER = 1 << 18
 
 TONEMAP_NONE, TONEMAP_CBRT = 0, 1
 

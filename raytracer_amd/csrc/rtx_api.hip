@@ -110,7 +110,8 @@ struct Workspace {
     size_t cand_capacity = 0;
     uint32_t* hit_index = nullptr;          // per ray: compact index among the level's hits
     uint32_t* perm = nullptr;               // shading order (material sort)
-    uint32_t* bins = nullptr;               // 2 * kBins: histogram, next free place per bin
+    uint32_t* bins = nullptr;               // kBins bin totals of the sort in progress (2 * kBins words kept)
+    uint32_t* tile_hist = nullptr;          // kBins x tiles: per bin and tile of kTileRays rays, count / first place
     double* sample = nullptr;               // 3 per slot
     uint32_t* counts = nullptr;             // ring of four (queue length, lit hits) pairs, indexed by level % 4
     unsigned long long* work = nullptr;     // 8 work counters, [8] shadow rays, [9] gather rays, [10..11] SIMD efficiency, [12] secondary rays
@@ -144,7 +145,7 @@ size_t queue_bytes(size_t cap)
 {
     auto al = [](size_t b) { return ((b + 255) / 256) * 256; };     // as carve() rounds
     size_t per_queue = 9 * al(cap * 8) + 3 * al(cap * 4) + al(cap * 4) + al(cap * 8);
-    return 2 * per_queue + 2 * al(cap * 4) + al(cap * 3 * 8) + 6 * al(cap * 8);
+    return 2 * per_queue + 2 * al(cap * 4) + al(cap * 3 * 8) + 6 * al(cap * 8) + al((size_t)kBins * ((cap + kTileRays - 1) / kTileRays) * 4);
 }
 
 // Device time per stage: event pairs are recorded on the library stream without
@@ -282,6 +283,7 @@ void lay_out_queues(Workspace& w, char* p, size_t cap)
     w.gq.ox = carve<double>(p, cap); w.gq.oy = carve<double>(p, cap); w.gq.oz = carve<double>(p, cap);
     w.perm = carve<uint32_t>(p, cap);
     w.sample = carve<double>(p, cap * 3);
+    w.tile_hist = carve<uint32_t>(p, (size_t)kBins * ((cap + kTileRays - 1) / kTileRays));
     w.capacity = cap;
 }
 void lay_out_shadow(Workspace& w, char* p, size_t shadow_cap)
@@ -887,7 +889,7 @@ static void hand_out_stats(rtx_scene* sc, rtx_stats* out)
 static int launch_trace(rtx_scene* sc, Workspace& ws, hipStream_t stream, const double* ox, const double* oy, const double* oz,
                         const double* dx, const double* dy, const double* dz, const double* limit, uint32_t n,
                         const uint32_t* n_device, uint32_t seg, uint32_t flags, int32_t* hit_prim, double* hit_depth, bool count,
-                        const CameraQueue* camera = nullptr, bool light_rays_from_origin = false)
+                        const CameraQueue* camera = nullptr, bool light_rays_from_origin = false, const uint32_t* perm = nullptr)
 {
     CameraQueue cam;
     if (camera) cam = *camera; else std::memset(&cam, 0, sizeof cam);
@@ -927,7 +929,7 @@ static int launch_trace(rtx_scene* sc, Workspace& ws, hipStream_t stream, const 
     }
 #define RTX_LAUNCH_TRACE(COUNT, MODE)                                                                                  \
     hipLaunchKernelGGL((k_trace_pool<COUNT, MODE>), grid, block, 0, stream, sc->d, ox, oy, oz, dx, dy, dz, limit, n, \
-                       n_device, seg, linear, hit_prim, hit_depth, g, cam, light_rays_from_origin ? 1u : 0u)
+                       n_device, seg, linear, hit_prim, hit_depth, g, cam, light_rays_from_origin ? 1u : 0u, perm)
 #define RTX_LAUNCH_MODES(COUNT)                                                                   \
     switch (mode) {                                                                               \
     case 0: RTX_LAUNCH_TRACE(COUNT, 0); break;                                                    \
@@ -1113,6 +1115,11 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
     const uint32_t direct_store = (rd->flags & RTX_FLAG_ACCUMULATE_SAMPLES) ? 0u
                                   : (!whitted || (single_level && !p.atomic_samples)) ? (nn == 1 ? 2u : 1u) : 0u;
     const uint32_t kLongLevel = 4u << 20;
+    // Rays of the levels below the camera's are walked in the order of their direction bin
+    // (k_bin_count<1>): worth three more small launches once a level holds this many rays
+    uint32_t bin_rays_min = 1u << 16;
+    if (const char* env = std::getenv("RTX_BIN_RAYS_MIN")) { long v = std::atol(env); if (v >= 0) bin_rays_min = (uint32_t)std::min<long>(v, 0x7fffffffL); }
+    const bool bin_rays = !(rd->flags & (RTX_FLAG_QUEUE_ORDER | RTX_FLAG_REFILL_LANES));
 
     struct Lane {
         Workspace* w = nullptr;
@@ -1173,8 +1180,17 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
         CameraQueue cq;
         cq.p = lp; cq.sample = w.sample; cq.counts = w.counts; cq.on = lp.camera_queue;
         cq.clear_samples = direct_store ? 0u : 1u;
+        const uint32_t* walk_order = nullptr;
+        if (bin_rays && level > 0 && bound >= bin_rays_min) {
+            const uint32_t n_tiles = (bound + kTileRays - 1) / kTileRays;
+            hipLaunchKernelGGL(k_tile_count<1>, dim3(n_tiles), dim3(kBlock), 0, st, sc->d, q, bound, n_dev, n_tiles, w.tile_hist, w.bins);
+            hipLaunchKernelGGL(k_tile_scan, dim3(kBins), dim3(kBlock), 0, st, n_tiles, w.tile_hist, w.bins);
+            hipLaunchKernelGGL(k_tile_scatter<1>, dim3(n_tiles), dim3(kBlock), 0, st, sc->d, q, bound, n_dev, n_tiles, w.tile_hist, w.bins, w.perm);
+            HIP_TRY(hipGetLastError());
+            walk_order = w.perm;
+        }
         int r = launch_trace(sc, w, st, q.ox, q.oy, q.oz, q.dx, q.dy, q.dz, nullptr, bound, n_dev, 0, rd->flags, q.hit_prim,
-                             (rd->flags & RTX_FLAG_REFILL_LANES) ? q.hit_depth : nullptr, count_work, &cq);
+                             (rd->flags & RTX_FLAG_REFILL_LANES) ? q.hit_depth : nullptr, count_work, &cq, false, walk_order);
         if (r != RTX_OK) return r;
         L.trace_timer_p->end(&local.ms_traverse);
         local.traverse_launches++;
@@ -1184,9 +1200,10 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
             L.timer_p->begin();
             const uint32_t* perm = nullptr;
             if (rd->flags & RTX_FLAG_SORT_MATERIAL) {       // exact lengths here (sync_every_level)
-                hipLaunchKernelGGL(k_bin_count, grid_for(bound), dim3(kBlock), 0, st, sc->d, q.hit_prim, bound, w.bins);
-                hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBins), 0, st, w.bins);
-                hipLaunchKernelGGL(k_bin_scatter, grid_for(bound), dim3(kBlock), 0, st, sc->d, q.hit_prim, bound, w.bins, w.perm);
+                const uint32_t n_tiles = (bound + kTileRays - 1) / kTileRays;
+                hipLaunchKernelGGL(k_tile_count<0>, dim3(n_tiles), dim3(kBlock), 0, st, sc->d, q, bound, nullptr, n_tiles, w.tile_hist, w.bins);
+                hipLaunchKernelGGL(k_tile_scan, dim3(kBins), dim3(kBlock), 0, st, n_tiles, w.tile_hist, w.bins);
+                hipLaunchKernelGGL(k_tile_scatter<0>, dim3(n_tiles), dim3(kBlock), 0, st, sc->d, q, bound, nullptr, n_tiles, w.tile_hist, w.bins, w.perm);
                 perm = w.perm;
             }
             hipLaunchKernelGGL(k_shade_path, grid_for(bound), dim3(kBlock), 0, st, sc->d, lp, q, bound, n_dev, perm, nq, next_len, w.sample);

@@ -643,3 +643,44 @@ def test_sequence_prefetch_gives_the_same_frames(gpu):
                                 camera=scenes.orbit_camera(times[0], radius=30.0, height=6.0))
         again, _ = ds.render(rd)
     assert np.array_equal(again, frames[(True, 0)])
+
+
+@pytest.mark.parametrize("kind", ["path", "path_sorted_shading", "whitted_refract", "noalloc"])
+def test_direction_binned_walk_order_gives_identical_images(gpu, monkeypatch, kind):
+    """Levels below the camera's are walked in the order of the rays' direction bins (forced here at
+    a small size); RTX_FLAG_QUEUE_ORDER walks them as queued.  Same hits per ray, so the same image
+    bit for bit, the same ray counts and the same traversal work, over chunks, passes and lanes."""
+    import torch
+    flags = abi.FLAG_COUNTERS
+    if kind in ("path", "path_sorted_shading", "noalloc"):
+        scene, cam = scenes.mesh_scene(slices=60, stacks=30, ggx=True)
+        scene.sphere((0.0, 10.0, 0.0), 2.0, scene.material("PlainWhiteTees", emission=(8.0, 8.0, 8.0)))
+        kw = dict(integrator=abi.INTEGRATOR_PATH, n=2, max_depth=6, bias=1e-3, passes=2, seed=8)
+        if kind == "path_sorted_shading":
+            flags |= abi.FLAG_SORT_MATERIAL
+    else:
+        scene, cam = scenes.whitted_scene()
+        kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=2, max_depth=5)
+    desc = scene.frame(0.2)
+    monkeypatch.setenv("RTX_BIN_RAYS_MIN", "1")
+    monkeypatch.setenv("RTX_TWO_LANE_MIN", "128")
+    monkeypatch.setenv("RTX_MAX_PATHS", "16384")
+    with gpu.DeviceScene(desc) as ds:
+        if kind == "noalloc":
+            rd = scenes.render_desc(150, 90, camera=cam, **kw)
+            a = torch.zeros((90, 150, 3), dtype=torch.float32, device="cuda")
+            b = torch.zeros_like(a)
+            ds.render_device_noalloc(rd, a.data_ptr())
+            rd.flags |= abi.FLAG_QUEUE_ORDER
+            ds.render_device_noalloc(rd, b.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and float(a.max()) > 0
+            return
+        a, sa = ds.render(scenes.render_desc(150, 90, camera=cam, flags=flags, **kw))
+        b, sb = ds.render(scenes.render_desc(150, 90, camera=cam, flags=flags | abi.FLAG_QUEUE_ORDER, **kw))
+    _same_ray_counts(sa, sb)
+    assert sa.rays_secondary > 0
+    for k in ("content_tests", "triangle_tests", "sphere_tests", "aabb_tests", "hits_accepted", "fallback_rays"):
+        assert getattr(sa, k) == getattr(sb, k), k
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.isfinite(a).all() and a.max() > 0
