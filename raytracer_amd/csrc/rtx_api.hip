@@ -750,7 +750,9 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     up(s->textures, (size_t)s->n_textures, &d.textures);
     up(s->texels, (size_t)s->n_texel_bytes, &d.texels);
     up(s->lights, (size_t)s->n_lights, &d.lights);
-    // the host arrays (the caller's and the tables above) are read until here
+    // Ordering: the uploads ran on the copy stream; finish() waits for them on the host, so every
+    // later call on any stream and through any handle (clones share these arrays, read-only) sees
+    // them complete.  The host arrays (the caller's and the tables above) are read until here.
     { hipError_t done = B.finish(); if (e == hipSuccess) e = done; }
     if (e != hipSuccess) {
         delete sc;
@@ -764,7 +766,16 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
 int rtx_scene_set_stream(rtx_scene* sc, void* hip_stream)
 {
     if (!sc) return fail(RTX_ERR_INVALID, "null scene");
-    sc->stream = static_cast<hipStream_t>(hip_stream);
+    hipStream_t next = static_cast<hipStream_t>(hip_stream);
+    if (next != sc->stream && sc->ws[0].counts) {
+        // Ordering: everything a handle queues -- its lanes are forked from and joined to the scene's
+        // stream -- is ordered by that stream, and the handle's queues and counters are reused by
+        // the next call.  Work still running on the old stream would race with calls queued on the
+        // new one, so the old stream is drained before the switch.
+        USE_DEVICE(sc->device);
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+    }
+    sc->stream = next;
     return RTX_OK;
 }
 
@@ -808,7 +819,10 @@ int rtx_trace_closest(rtx_scene* sc, const double* origin, const double* directi
     const double *d_o = nullptr, *d_d = nullptr;
     HIP_TRY(tmp.upload(origin, n * 3, &d_o));
     HIP_TRY(tmp.upload(direction, n * 3, &d_d));
-    HIP_TRY(tmp.finish());          // the copies run on a stream of their own: the kernel below must not overtake them
+    // Ordering: the ray uploads run on the buffers' own non-blocking copy stream, which is ordered
+    // with nothing else; finish() waits for them on the host, so the launch on the scene's stream
+    // below cannot overtake them (the blocking hipMemcpy calls further down are complete when they return).
+    HIP_TRY(tmp.finish());
     auto dalloc = [&](size_t bytes, void** p) -> hipError_t {
         hipError_t e = hipMalloc(p, bytes);
         if (e == hipSuccess) tmp.ptrs.push_back(*p);
@@ -1090,6 +1104,10 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
     hipEvent_t& ev1 = ev.b;
     if (stats) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, user)); }
     const bool keep_times = !fixed && (stats != nullptr || sc->async);
+    // Ordering: the lanes wait for this event, i.e. for everything the caller queued on the scene's
+    // stream before this call (the previous frame's render and present through this handle, which
+    // used the same queues, included); at the end the scene's stream waits for both lanes' join
+    // events, so to the caller the call is ordered as if all of it ran on the scene's stream.
     if (n_lanes > 1) HIP_TRY(hipEventRecord(sc->fork_event, user));
 
     // rayTrace spawns nothing when no material refracts and the mirror extension is off
@@ -1118,8 +1136,12 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
     // Rays of the levels below the camera's are walked in the order of their direction bin
     // (k_bin_count<1>): worth three more small launches once a level holds this many rays
     uint32_t bin_rays_min = 1u << 16;
+    uint32_t bin_shapes_min = 1024;
+    if (const char* env = std::getenv("RTX_BIN_SHAPES_MIN")) { long v = std::atol(env); if (v >= 0) bin_shapes_min = (uint32_t)std::min<long>(v, 0x7fffffffL); }
     if (const char* env = std::getenv("RTX_BIN_RAYS_MIN")) { long v = std::atol(env); if (v >= 0) bin_rays_min = (uint32_t)std::min<long>(v, 0x7fffffffL); }
-    const bool bin_rays = !(rd->flags & (RTX_FLAG_QUEUE_ORDER | RTX_FLAG_REFILL_LANES));
+    // (and only for scenes whose walk is long enough to gain: in a scene of a few shapes the three
+    // launches cost more than the whole traversal -- lens scene, 1080p depth 8: 1.17 -> 1.39 ms)
+    const bool bin_rays = !(rd->flags & (RTX_FLAG_QUEUE_ORDER | RTX_FLAG_REFILL_LANES)) && sc->d.n_shapes >= bin_shapes_min;
 
     struct Lane {
         Workspace* w = nullptr;
@@ -1320,6 +1342,7 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
                 Lane& L = lanes[k];
                 if (!L.alive) continue;
                 if (L.want_sync) {
+                    // (the pinned word was written by a copy queued on this lane's stream after the level's kernels)
                     HIP_TRY(hipStreamSynchronize(L.st));
                     L.want_sync = false;
                     L.bound = L.w->host_counts[0];
@@ -1421,6 +1444,9 @@ int rtx_present_device(rtx_scene* sc, const float* accum, uint32_t width, uint32
     if (passes == 0 || tonemap > RTX_TONEMAP_CBRT) return fail(RTX_ERR_INVALID, "bad passes / tonemap");
     if (height > 65535u) return fail(RTX_ERR_LIMIT, "more than 65535 rows");
     USE_DEVICE(sc->device);
+    // Ordering: queued on the scene's stream behind the render calls that filled `accum` through this
+    // handle; a caller that renders through one handle and presents through another orders the two
+    // streams itself.
     hipLaunchKernelGGL(k_present, dim3(grid_for((size_t)width * 3).x, height), dim3(kBlock), 0, sc->stream, accum, width, height,
                        (float)passes, tonemap, flip ? 1u : 0u, sc->srgb_thresholds, rgb8);
     HIP_TRY(hipGetLastError());

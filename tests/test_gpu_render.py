@@ -663,6 +663,7 @@ def test_direction_binned_walk_order_gives_identical_images(gpu, monkeypatch, ki
         kw = dict(integrator=abi.INTEGRATOR_WHITTED, n=2, max_depth=5)
     desc = scene.frame(0.2)
     monkeypatch.setenv("RTX_BIN_RAYS_MIN", "1")
+    monkeypatch.setenv("RTX_BIN_SHAPES_MIN", "0")
     monkeypatch.setenv("RTX_TWO_LANE_MIN", "128")
     monkeypatch.setenv("RTX_MAX_PATHS", "16384")
     with gpu.DeviceScene(desc) as ds:
