@@ -533,6 +533,16 @@ constexpr uint32_t kCandReference = 0xfffffffeu;    // not walked (non-finite ra
 constexpr uint32_t kCandTie = 0x80000000u;          // flag: another shape ties at the winning depth
 // otherwise: the winning candidate's shape id.
 
+// 64 aligned bytes at a wave-uniform address through the scalar cache (a read; the scalar
+// cache is never written through).
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+RTX_DEV u32x16 scalar_load_64(const void* p)
+{
+    u32x16 v;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+}
+
 // Optimistic form: the BVH walk treats every geometric candidate as genuine, so its loop
 // holds no long divergent section; the winner is verified once, after the loop, when the
 // lanes of the wave have reconverged.  Returns false when the optimistic answer cannot be
@@ -562,9 +572,21 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     bool done = false;
     while (!done) {
         if (node >= 0) {
-            // one node = four 16-byte loads
-            const float4* n = reinterpret_cast<const float4*>(s.bvh_nodes + node);
-            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            float4 n0, n1, n2, n3;
+            const int32_t first_node = __builtin_amdgcn_readfirstlane(node);
+            if (__all(node == first_node)) {
+                // every lane of the wave that stands at a node stands at this one: the node comes
+                // through the scalar cache in one load, not through the vector memory pipeline
+                const u32x16 v = scalar_load_64(s.bvh_nodes + first_node);
+                n0 = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+                n1 = make_float4(__uint_as_float(v[4]), __uint_as_float(v[5]), __uint_as_float(v[6]), __uint_as_float(v[7]));
+                n2 = make_float4(__uint_as_float(v[8]), __uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11]));
+                n3 = make_float4(__uint_as_float(v[12]), __uint_as_float(v[13]), __uint_as_float(v[14]), __uint_as_float(v[15]));
+            } else {
+                // one node = four 16-byte loads
+                const float4* n = reinterpret_cast<const float4*>(s.bvh_nodes + node);
+                n0 = n[0]; n1 = n[1]; n2 = n[2]; n3 = n[3];
+            }
             const d3 lb0 = mk(n0.x, n0.y, n0.z), lb1 = mk(n0.w, n1.x, n1.y);
             const d3 rb0 = mk(n1.z, n1.w, n2.x), rb1 = mk(n2.y, n2.z, n2.w);
             double lmin, lmax, rmin, rmax;
