@@ -543,6 +543,15 @@ RTX_DEV u32x16 scalar_load_64(const void* p)
     return v;
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+RTX_DEV u32x4 scalar_load_16(const void* p)
+{
+    u32x4 v;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+}
+RTX_DEV double dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+
 // Optimistic form: the BVH walk treats every geometric candidate as genuine, so its loop
 // holds no long divergent section; the winner is verified once, after the loop, when the
 // lanes of the wave have reconverged.  Returns false when the optimistic answer cannot be
@@ -609,13 +618,28 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
             const uint32_t code = (uint32_t)~node;
             const BvhPrim* q = s.bvh_prims + (code >> 3);
             const uint32_t count = (code & 7u) + 1u;
-            for (uint32_t k = 0; k < count; ++k, ++q) {
+            // all lanes that stand at a leaf stand at this one: its records come through the scalar cache
+            const int32_t first_leaf = __builtin_amdgcn_readfirstlane(node);
+            const bool same_leaf = __all(node == first_leaf);
+            const BvhPrim* uq = s.bvh_prims + ((uint32_t)~first_leaf >> 3);
+            for (uint32_t k = 0; k < count; ++k, ++q, ++uq) {
                 // Shape::rayAABB && rayHit (KDTree.cpp:208-211) commute: rayHit first, and the
                 // shape's box is only fetched for a hit that could change the result
                 // the whole record in one go: ids and positions arrive together instead of the
                 // positions waiting for the type to be known
-                const d3 ta = ld3(q->p), tb = ld3(q->p + 3), tc = ld3(q->p + 6);
-                uint32_t shape = q->shape, info = q->info;
+                d3 ta, tb, tc;
+                uint32_t shape, info;
+                if (same_leaf) {
+                    const u32x16 a = scalar_load_64(uq);
+                    const u32x4 b = scalar_load_16(reinterpret_cast<const char*>(uq) + 64);
+                    ta = mk(dbl(a[0], a[1]), dbl(a[2], a[3]), dbl(a[4], a[5]));
+                    tb = mk(dbl(a[6], a[7]), dbl(a[8], a[9]), dbl(a[10], a[11]));
+                    tc = mk(dbl(a[12], a[13]), dbl(a[14], a[15]), dbl(b[0], b[1]));
+                    shape = b[2]; info = b[3];
+                } else {
+                    ta = ld3(q->p); tb = ld3(q->p + 3); tc = ld3(q->p + 6);
+                    shape = q->shape; info = q->info;
+                }
                 uint32_t type = info & 3u, idx = info >> 2;
                 double depth = kInf;
                 uint32_t rp = shape;
