@@ -196,6 +196,80 @@ RTX_DEV void trace_lane(const DScene& s, d3 o, d3 d, bool linear, int32_t* stack
     }
 }
 
+// ---- loads through the scalar cache ------------------------------------------------------------
+// The walks wait on chains of dependent loads, and a load through the scalar cache returns sooner
+// than one through the vector memory pipeline.  Where every active lane of the wave asks for the
+// same address -- neighbouring rays at the same node, leaf or shape -- the value is fetched once
+// with a scalar load (reads only: the scalar cache is never written through).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+// (the address is the same in every active lane: say so to the compiler)
+RTX_DEV const void* uniform_address(const void* p)
+{
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    return (const void*)(((uint64_t)hi << 32) | lo);
+}
+RTX_DEV uint32_t scalar_load_4(const void* p)
+{
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(uniform_address(p)));
+    return v;
+}
+RTX_DEV u32x2 scalar_load_8(const void* p)
+{
+    u32x2 v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(uniform_address(p)));
+    return v;
+}
+RTX_DEV u32x4 scalar_load_16(const void* p)
+{
+    u32x4 v;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(uniform_address(p)));
+    return v;
+}
+RTX_DEV u32x8 scalar_load_32(const void* p)
+{
+    u32x8 v;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(uniform_address(p)));
+    return v;
+}
+RTX_DEV u32x16 scalar_load_64(const void* p)
+{
+    u32x16 v;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(uniform_address(p)));
+    return v;
+}
+RTX_DEV double dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+// index of the first active lane, and whether all active lanes hold it
+RTX_DEV bool wave_uniform(uint32_t index, uint32_t& first)
+{
+    first = (uint32_t)__builtin_amdgcn_readfirstlane((int)index);
+    return __all(index == first);
+}
+
+// a shape's box (48 bytes), through the scalar cache when `uniform` (all active lanes ask for shape `first`)
+struct Box6 { d3 mn, mx; };
+RTX_DEV Box6 load_prim_box(const PrimBox* __restrict__ boxes, uint32_t shape, bool uniform, uint32_t first)
+{
+    Box6 r;
+    if (uniform) {
+        const char* p = reinterpret_cast<const char*>(boxes + first);
+        const u32x8 a = scalar_load_32(p);
+        const u32x4 b = scalar_load_16(p + 32);
+        r.mn = mk(dbl(a[0], a[1]), dbl(a[2], a[3]), dbl(a[4], a[5]));
+        r.mx = mk(dbl(a[6], a[7]), dbl(b[0], b[1]), dbl(b[2], b[3]));
+    } else {
+        const PrimBox* b = boxes + shape;
+        r.mn = mk(b->bmin[0], b->bmin[1], b->bmin[2]);
+        r.mx = mk(b->bmax[0], b->bmax[1], b->bmax[2]);
+    }
+    return r;
+}
+
 // ---- culled traversal: same answer, less work ---------------------------------------------------
 // shootRay's result is the lexicographic minimum of (depth, position in the reference's
 // visit order) over the candidates the reference's walk generates: it replaces the best
@@ -483,30 +557,63 @@ RTX_DEV bool member_through_point(const DScene& s, uint32_t shape, d3 p, d3 o, d
 RTX_DEV int32_t locate_leaf(const DScene& s, int32_t node, d3 p)
 {
     while (node >= 0) {
-        const KdSplit k = s.kd_split[node];
+        uint32_t first;
+        KdSplit k;
+        if (wave_uniform((uint32_t)node, first)) {
+            const u32x4 v = scalar_load_16(s.kd_split + first);
+            k.value = dbl(v[0], v[1]); k.lesser_axis = (int32_t)v[2]; k.greater = (int32_t)v[3];
+        } else {
+            k = s.kd_split[node];
+        }
         node = pick(p, k.lesser_axis & 3) <= k.value ? (k.lesser_axis >> 2) : k.greater;
     }
     return node;
 }
 
-RTX_DEV bool leaf_holds(const DScene& s, uint32_t shape, uint32_t leaf)
+// whether `leaf` is among the leaves of `shape`; shape_uniform: all active lanes ask about shape `first_shape`
+RTX_DEV bool leaf_holds(const DScene& s, uint32_t shape, uint32_t leaf, bool shape_uniform = false, uint32_t first_shape = 0u)
 {
-    const uint32_t first = s.prim_leaf_first[shape], end = s.prim_leaf_first[shape + 1];
-    uint32_t at = lower_bound_u32(s.prim_leaf_ids, first, end, leaf);
+    uint32_t lo, hi;
+    if (shape_uniform) {
+        const u32x2 r = scalar_load_8(s.prim_leaf_first + first_shape);
+        lo = r[0]; hi = r[1];
+    } else {
+        lo = s.prim_leaf_first[shape]; hi = s.prim_leaf_first[shape + 1];
+    }
+    const uint32_t end = hi;
+    uint32_t first_leaf;
+    if (shape_uniform && wave_uniform(leaf, first_leaf)) {
+        // the whole search runs on scalar loads: every lane looks for the same leaf in the same list
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (scalar_load_4(s.prim_leaf_ids + mid) < first_leaf) lo = mid + 1; else hi = mid;
+        }
+        return lo < end && scalar_load_4(s.prim_leaf_ids + lo) == first_leaf;
+    }
+    uint32_t at = lower_bound_u32(s.prim_leaf_ids, lo, hi, leaf);
     return at < end && s.prim_leaf_ids[at] == leaf;
+}
+
+RTX_DEV Box6 load_leaf_cell(const DScene& s, uint32_t leaf)
+{
+    uint32_t first;
+    const bool uniform = wave_uniform(leaf, first);
+    return load_prim_box(s.leaf_cell, leaf, uniform, first);
 }
 
 RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 o, d3 d, double t, double margin)
 {
-    const int32_t lca = s.prim_lca[shape];
+    uint32_t first_shape;
+    const bool shape_uniform = wave_uniform(shape, first_shape);
+    const int32_t lca = shape_uniform ? (int32_t)scalar_load_4(s.prim_lca + first_shape) : s.prim_lca[shape];
     d3 p = o + (d * t);
     uint32_t leaf = (uint32_t)~locate_leaf(s, lca, p);
-    const PrimBox* c = s.leaf_cell + leaf;
+    Box6 c = load_leaf_cell(s, leaf);
     // how far each coordinate is short of being `margin` inside the cell (<= 0: fine)
-    const double lx = (c->bmin[0] + margin) - p.x, hx = p.x - (c->bmax[0] - margin);
-    const double ly = (c->bmin[1] + margin) - p.y, hy = p.y - (c->bmax[1] - margin);
-    const double lz = (c->bmin[2] + margin) - p.z, hz = p.z - (c->bmax[2] - margin);
-    if (lx <= 0.0 && hx <= 0.0 && ly <= 0.0 && hy <= 0.0 && lz <= 0.0 && hz <= 0.0) return leaf_holds(s, shape, leaf);
+    const double lx = (c.mn.x + margin) - p.x, hx = p.x - (c.mx.x - margin);
+    const double ly = (c.mn.y + margin) - p.y, hy = p.y - (c.mx.y - margin);
+    const double lz = (c.mn.z + margin) - p.z, hz = p.z - (c.mx.z - margin);
+    if (lx <= 0.0 && hx <= 0.0 && ly <= 0.0 && hy <= 0.0 && lz <= 0.0 && hz <= 0.0) return leaf_holds(s, shape, leaf, shape_uniform, first_shape);
     // step back along the ray: a face the point is too close to must be one the ray leaves through
     double back = 0.0;
     if (lx > 0.0) { if (!(d.x < 0.0)) return false; back = __builtin_fmax(back, (lx + margin) / -d.x); }
@@ -519,11 +626,11 @@ RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 o, d3 d, double 
     if (!(t2 > 0.0)) return false;
     p = o + (d * t2);
     leaf = (uint32_t)~locate_leaf(s, lca, p);
-    c = s.leaf_cell + leaf;
-    bool inside = p.x - margin >= c->bmin[0] && p.x + margin <= c->bmax[0] &&
-                  p.y - margin >= c->bmin[1] && p.y + margin <= c->bmax[1] &&
-                  p.z - margin >= c->bmin[2] && p.z + margin <= c->bmax[2];
-    return inside && leaf_holds(s, shape, leaf);
+    c = load_leaf_cell(s, leaf);
+    bool inside = p.x - margin >= c.mn.x && p.x + margin <= c.mx.x &&
+                  p.y - margin >= c.mn.y && p.y + margin <= c.mx.y &&
+                  p.z - margin >= c.mn.z && p.z + margin <= c.mx.z;
+    return inside && leaf_holds(s, shape, leaf, shape_uniform, first_shape);
 }
 
 // What a walk leaves for a separate verification pass (k_verify), per ray:
@@ -532,25 +639,6 @@ constexpr uint32_t kCandSettled = 0xffffffffu;      // nothing to verify: no geo
 constexpr uint32_t kCandReference = 0xfffffffeu;    // not walked (non-finite ray): take the reference-order walk
 constexpr uint32_t kCandTie = 0x80000000u;          // flag: another shape ties at the winning depth
 // otherwise: the winning candidate's shape id.
-
-// 64 aligned bytes at a wave-uniform address through the scalar cache (a read; the scalar
-// cache is never written through).
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-RTX_DEV u32x16 scalar_load_64(const void* p)
-{
-    u32x16 v;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
-    return v;
-}
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-RTX_DEV u32x4 scalar_load_16(const void* p)
-{
-    u32x4 v;
-    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
-    return v;
-}
-RTX_DEV double dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 
 // Optimistic form: the BVH walk treats every geometric candidate as genuine, so its loop
 // holds no long divergent section; the winner is verified once, after the loop, when the
@@ -657,7 +745,8 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 if (!ok) continue;
                 if (ANYHIT ? !(depth <= limit) : !(depth <= best_depth)) continue;
                 double tmin, tmax;
-                slab_finite(s.prim_box + shape, o, inv, tmin, tmax);
+                const Box6 sb = load_prim_box(s.prim_box, shape, same_leaf, same_leaf ? (uint32_t)__builtin_amdgcn_readfirstlane((int)shape) : 0u);
+                slab_finite(sb.mn, sb.mx, o, inv, tmin, tmax);
                 if constexpr (COUNT) w.aabb++;
                 if (!(tmin <= tmax && tmax >= 0.0)) continue;
                 if constexpr (ANYHIT) {
