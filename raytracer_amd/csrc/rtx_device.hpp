@@ -407,15 +407,16 @@ RTX_DEV double light_attenuation(const rtx_light& l, double d, const double* att
     return (att[0] + (att[1] * d) + (att[2] * (d * d)));
 }
 
-// lightingFunction (Raytracer.cpp:187-197)
-RTX_DEV d3 lighting(const DScene& s, d3 ray_inv_dir, d3 ldir, d3 normal, double u, double v, double attenuation,
-                    const rtx_material& m, d3 lcolor)
+// lightingFunction (Raytracer.cpp:187-197).  `color` and `ns` are the material's colour and
+// specular exponent at the hit (material_color, sample_scalar of ns_fn): the same for every light
+// sample of a hit, so the caller samples them once.
+RTX_DEV d3 lighting(d3 ray_inv_dir, d3 ldir, d3 normal, double attenuation, d3 color, double ns, d3 lcolor)
 {
     d3 refl = normalize3((normal * (dot(ldir, normal) * 2.0)) - ldir);
-    double spec = pow(gmax(0.0, dot(refl, ray_inv_dir)), sample_scalar(s, m.ns_fn, m.ns, u, v));
+    double spec = pow(gmax(0.0, dot(refl, ray_inv_dir)), ns);
     d3 specular = (lcolor * spec) / attenuation;
     double diff = gmax(0.0, dot(normal, ldir));
-    d3 diffuse = ((material_color(s, m, u, v) * lcolor) * diff) / attenuation;
+    d3 diffuse = ((color * lcolor) * diff) / attenuation;
     return diffuse + specular;
 }
 

@@ -1678,6 +1678,8 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
             local = material_color(s, m, h.u, h.v);
         } else {
             d3 direct = mk(0, 0, 0), global = mk(0, 0, 0);
+            const d3 mcolor = material_color(s, m, h.u, h.v);
+            const double mns = sample_scalar(s, m.ns_fn, m.ns, h.u, h.v);
             const uint32_t h_index = hit_index[i];
             const uint32_t stride = p.seg;
             uint32_t k = h_index, g = h_index;
@@ -1698,7 +1700,7 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
                     if (ldist < sq.hit_depth[k]) {
                         if (!p.light_rays_from_origin) ld = mk(sq.dx[k], sq.dy[k], sq.dz[k]);
                         double att = light_attenuation(l, ldist, p.d.attenuation);
-                        direct = direct + lighting(s, inv_dir, ld, h.normal, h.u, h.v, att, m, ld3(l.color));
+                        direct = direct + lighting(inv_dir, ld, h.normal, att, mcolor, mns, ld3(l.color));
                     }
                 }
                 direct = direct / (double)samples;          // inside the light loop (:498)
@@ -1716,7 +1718,7 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
                                 dist = distance3(go, go + (gd * t));
                             }
                             double att = light_attenuation(l, dist, p.d.attenuation);
-                            global = global + lighting(s, inv_dir, gd, h.normal, h.u, h.v, att, m, ld3(l.color));
+                            global = global + lighting(inv_dir, gd, h.normal, att, mcolor, mns, ld3(l.color));
                         } else {
                             global = global + (clear * 0.04);
                         }
