@@ -669,30 +669,30 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     bool done = false;
     while (!done) {
         if (node >= 0) {
-            float4 n0, n1, n2, n3;
+            double lmin, lmax, rmin, rmax;
+            int32_t left, right;
             const int32_t first_node = __builtin_amdgcn_readfirstlane(node);
             if (__all(node == first_node)) {
                 // every lane of the wave that stands at a node stands at this one: the node comes
-                // through the scalar cache in one load, not through the vector memory pipeline
+                // through the scalar cache in one load, not through the vector memory pipeline, and
+                // the slab arithmetic takes its boxes straight from the scalar registers
                 const u32x16 v = scalar_load_64(s.bvh_nodes + first_node);
-                n0 = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-                n1 = make_float4(__uint_as_float(v[4]), __uint_as_float(v[5]), __uint_as_float(v[6]), __uint_as_float(v[7]));
-                n2 = make_float4(__uint_as_float(v[8]), __uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11]));
-                n3 = make_float4(__uint_as_float(v[12]), __uint_as_float(v[13]), __uint_as_float(v[14]), __uint_as_float(v[15]));
+                slab_finite(mk(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2])),
+                            mk(__uint_as_float(v[3]), __uint_as_float(v[4]), __uint_as_float(v[5])), o, inv, lmin, lmax);
+                slab_finite(mk(__uint_as_float(v[6]), __uint_as_float(v[7]), __uint_as_float(v[8])),
+                            mk(__uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11])), o, inv, rmin, rmax);
+                left = (int32_t)v[12]; right = (int32_t)v[13];
             } else {
                 // one node = four 16-byte loads
                 const float4* n = reinterpret_cast<const float4*>(s.bvh_nodes + node);
-                n0 = n[0]; n1 = n[1]; n2 = n[2]; n3 = n[3];
+                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                slab_finite(mk(n0.x, n0.y, n0.z), mk(n0.w, n1.x, n1.y), o, inv, lmin, lmax);
+                slab_finite(mk(n1.z, n1.w, n2.x), mk(n2.y, n2.z, n2.w), o, inv, rmin, rmax);
+                left = __float_as_int(n3.x); right = __float_as_int(n3.y);
             }
-            const d3 lb0 = mk(n0.x, n0.y, n0.z), lb1 = mk(n0.w, n1.x, n1.y);
-            const d3 rb0 = mk(n1.z, n1.w, n2.x), rb1 = mk(n2.y, n2.z, n2.w);
-            double lmin, lmax, rmin, rmax;
-            slab_finite(lb0, lb1, o, inv, lmin, lmax);
-            slab_finite(rb0, rb1, o, inv, rmin, rmax);
             if constexpr (COUNT) w.content += 2;
             bool hl = lmin <= lmax && lmax >= 0.0 && !(lmin > bound);
             bool hr = rmin <= rmax && rmax >= 0.0 && !(rmin > bound);
-            int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
             if (hl && hr) {
                 bool left_first = lmin <= rmin;
                 stack[sp * kTraceBlock] = left_first ? right : left;
