@@ -1,0 +1,42 @@
+"""bench.py's N > 1 path on the one GPU of a test box: two ranks share the card and gather through
+host memory (BENCH_BACKEND=gloo); RCCL itself needs one GPU per rank.  What is checked is what a
+multi-GPU node runs apart from the transport: device selection per rank, frames of the sequence dealt
+out to the ranks, interleaved row groups of one 16-spp frame per rank, the gathers, the max-over-ranks
+timing and the one JSON line of rank 0."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_print_one_line_with_both_scalings(gpu):
+    env = dict(os.environ, BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--repeats", "0", "--frames16", "2", "--width", "320", "--height", "184", "--mesh", "teapot", "--no-cpu-baseline",
+           "--no-serial-leg"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["steps"] == 4 and out["warmup"] == 2
+    for kind in ("whitted_area_light", "path_ggx"):
+        f = out["frame_16spp"][kind]
+        assert f["n_gpus"] == 2 and f["scaling"] == "strong" and f["ms_per_frame"] > 0
+        assert out["strong_scaling"][kind]["n_gpus"] == 2
+    # the rays of the frames the two ranks rendered, summed: more than one rank's share of the steps
+    assert out["rays_per_frame"] > 320 * 184
