@@ -1134,7 +1134,7 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
                                   : (!whitted || (single_level && !p.atomic_samples)) ? (nn == 1 ? 2u : 1u) : 0u;
     const uint32_t kLongLevel = 4u << 20;
     // Rays of the levels below the camera's are walked in the order of their direction bin
-    // (k_bin_count<1>): worth three more small launches once a level holds this many rays
+    // (k_tile_count<1>): worth three more small launches once a level holds this many rays
     uint32_t bin_rays_min = 1u << 16;
     uint32_t bin_shapes_min = 1024;
     if (const char* env = std::getenv("RTX_BIN_SHAPES_MIN")) { long v = std::atol(env); if (v >= 0) bin_shapes_min = (uint32_t)std::min<long>(v, 0x7fffffffL); }

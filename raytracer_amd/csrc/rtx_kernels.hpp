@@ -946,7 +946,7 @@ k_trace_api(DScene s, const double* __restrict__ origin, const double* __restric
 // MODE 0: the reference's walk order; 1 / 2: culled KD walk, closest hit / any hit with
 // depth <= limit[i] (depth = +inf when there is none); 3 / 4: the same through the BVH.
 // `perm` (flat queues only, optional) lists the queue entries in the order they are to be
-// walked: thread j takes ray perm[j] (rays binned by direction, see k_bin_count).
+// walked: thread j takes ray perm[j] (rays binned by direction, see k_tile_count).
 // Origin, direction and (any-hit walks) light distance of ray i of a pool launch: stored in the
 // queue, or the camera's for a level-0 queue that is not stored, or the one light's for a
 // shadow queue that holds origins only.
