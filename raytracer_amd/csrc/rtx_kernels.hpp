@@ -1360,7 +1360,7 @@ RTX_DEV Rng ray_rng(const RenderParams& p, const RayQueue& q, uint32_t i, uint32
 //   KEY 0, the material a ray hit (0 = miss, else 1 + material mod 63), for the shading kernels:
 //     the branches of pathTrace (refract / mirror / diffuse / emissive, textured or not) are chosen
 //     by the material, so a wave whose rays all hit one material runs one of them;
-//   KEY 1, the ray's direction (an 8 x 8 grid over the octahedral map of the unit sphere), for the
+//   KEY 1, the ray's direction (a 4 x 4 grid over the octahedral map of the unit sphere), for the
 //     traversal of bounce rays.  The queue of a level below the camera's is in the order of the
 //     rays' parents -- neighbouring origins, directions all over the hemisphere -- and a wavefront
 //     walks as long as its longest ray while its lanes fetch nodes from all over the tree.  Rays
@@ -1369,7 +1369,8 @@ RTX_DEV Rng ray_rng(const RenderParams& p, const RayQueue& q, uint32_t i, uint32
 //     many rays that leave the scene at once (half of all bounce rays off an upward surface) end
 //     up in wavefronts of their own.  Measured on 4 M bounce rays off the backpack scene: 2.91 ms
 //     in queue order, 2.06 ms binned (1.98 ms fully sorted by direction and origin cell).
-constexpr uint32_t kBins = 64;
+constexpr uint32_t kDirSide = 4;             // direction bins per side of the octahedral square
+constexpr uint32_t kBins = kDirSide * kDirSide;
 
 RTX_DEV uint32_t shade_bin(const DScene& s, int32_t prim)
 {
@@ -1388,9 +1389,10 @@ RTX_DEV uint32_t direction_bin(double x, double y, double z)
         float qy = (1.0f - fabsf(px)) * (py < 0.0f ? -1.0f : 1.0f);
         px = qx; py = qy;
     }
-    int bx = (int)((px * 0.5f + 0.5f) * 8.0f), by = (int)((py * 0.5f + 0.5f) * 8.0f);
-    bx = min(max(bx, 0), 7); by = min(max(by, 0), 7);         // also what a NaN direction gets: (0, 0)
-    return (uint32_t)(by * 8 + bx);
+    const int side = (int)kDirSide;
+    int bx = (int)((px * 0.5f + 0.5f) * (float)side), by = (int)((py * 0.5f + 0.5f) * (float)side);
+    bx = min(max(bx, 0), side - 1); by = min(max(by, 0), side - 1);       // also what a NaN direction gets: (0, 0)
+    return (uint32_t)(by * side + bx);
 }
 
 template <int KEY>
