@@ -58,6 +58,7 @@ struct Builder {
     std::vector<double> centroid;       // 3 per prim
     std::vector<uint32_t> order;
     int spawn_depth = 0;                // levels (from the root) that may hand a subtree to another thread
+    bool all_axes = true;               // split on the best of the three axes, not on the widest one only
 
     Builder(const std::vector<PrimBox>& b, uint32_t n) : boxes(b), centroid(3 * (size_t)n), order(n)
     {
@@ -108,7 +109,6 @@ struct Builder {
         double best = std::numeric_limits<double>::max();
         int best_b = -1, best_axis = axis;
         double best_scale = 0.0;
-        static const bool all_axes = [] { const char* e = std::getenv("RTX_BVH_WIDEST_AXIS"); return !(e && e[0] == '1'); }();
         for (int ax = 0; ax < 3; ++ax) {
             if (!all_axes && ax != axis) continue;
             const double e = cb.mx[ax] - cb.mn[ax];
@@ -203,6 +203,7 @@ inline void build_bvh(const std::vector<PrimBox>& boxes, uint32_t n_shapes, BvhB
     out = BvhBuild();
     if (n_shapes == 0 || n_shapes > kBvhMaxShapes) { out.root = kBvhEmpty; return; }
     bvh_detail::Builder b(boxes, n_shapes);
+    if (const char* e = std::getenv("RTX_BVH_WIDEST_AXIS")) b.all_axes = e[0] != '1';
     unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     while ((1u << b.spawn_depth) < threads) ++b.spawn_depth;
     if (threads > 1) b.spawn_depth += 1;
