@@ -60,6 +60,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("names", nargs="*", default=["c1", "c2", "c3", "c4w", "c4p"])
     ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--c5-frames", type=int, default=2, help="frames of c5 (each about a second of GPU time and of host preparation)")
     ap.add_argument("--sort-material", action="store_true", help="shade pathTrace levels in material order")
     ap.add_argument("--refill-lanes", action="store_true", help="BVH walk with finished lanes refilled from the queue")
     ap.add_argument("--store-camera-rays", action="store_true", help="camera rays written by a generate kernel and read back")
@@ -78,7 +79,7 @@ def main():
     for name in args.names:
         scene, rd_of, fixed_t = table[name]()
         animated = fixed_t is None
-        frames = 2 if name == "c5" else args.frames
+        frames = min(args.frames, args.c5_frames) if name == "c5" else args.frames
         t0 = time.perf_counter()
         desc = scene.frame(0.0)
         t_host = time.perf_counter() - t0
