@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="further timed regions of --steps frames for the spread (the "
                                                            "first region is the reported one)")
     ap.add_argument("--frames16", type=int, default=10, help="frames timed per 16-spp workload")
+    ap.add_argument("--frames16-in-flight", type=int, default=3,
+                    help="frames of the 16-spp sequence kept in flight for the `pipelined` figure (0: leave it out)")
     ap.add_argument("--only", choices=["all", "main", "f16w", "f16p"], default="all",
                     help="run one workload only (profiling runs)")
     ap.add_argument("--pmc-run", action="store_true",
@@ -238,7 +240,8 @@ def main():
             if world > 1:
                 # the scaling figure of the 16-spp metric: one frame over all ranks (strong scaling);
                 # `value` above is frames of a sequence dealt out to the ranks (weak scaling)
-                out["strong_scaling"] = {k: {"ms_per_frame": v["ms_per_frame"], "Mrays_per_s": v["Mrays_per_s"], "n_gpus": world}
+                out["strong_scaling"] = {k: {"ms_per_frame": v["ms_per_frame"], "Mrays_per_s": v["Mrays_per_s"], "n_gpus": world,
+                                             "pipelined_ms_per_frame": (v.get("pipelined") or {}).get("ms_per_frame")}
                                          for k, v in f16.items()}
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -515,6 +518,9 @@ def frame_16spp(ctx, kind):
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt = mx[0].item()
     total_rays = tt[1].item()
+    pipelined = None
+    if args.frames16_in_flight > 0 and not args.pmc_run:
+        pipelined = pipelined_frames(ctx, kind, ds, rd_for, frames, args.frames16_in_flight)
     out = None
     if rank == 0:
         ms_per_frame = dt / frames * 1e3
@@ -542,10 +548,107 @@ def frame_16spp(ctx, kind):
             "roofline": roofline_block(args.walk, alg_bytes_frame * scale, acc["rays"], acc["ms_trav"], acc["launches"],
                                        ms_per_frame, cf, overlap=True, flops=flops_frame * scale),
         }
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_rows(desc, lambda tile: rd_for(1, 0, tile), W, H)
     ds.close()
     return out
+
+
+def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight):
+    """The same frames as a sequence with `in_flight` of them queued at a time (frame f through a
+    handle cloned from the scene, on stream f % in_flight): every rank renders its interleaved rows of
+    each frame, presents them and rank 0 gathers the presented rows; nothing waits on the host until
+    the end.  A level of a pathTrace frame lasts at least as long as its longest ray's chain of
+    dependent steps however few rays it holds, so a rank's share of ONE frame does not shrink with
+    the number of ranks the way its ray count does; frames in flight fill those tails with the next
+    frames' work.  Returns, on rank 0, the time per frame over all ranks (max over ranks) and the
+    rate; the figure to compare across N."""
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import abi
+    from raytracer_amd import dist as rdist
+    args, rank, world, dev, comm_dev, backend = (ctx[k] for k in ("args", "rank", "world", "dev", "comm_dev", "backend"))
+    W, H = args.width, args.height
+    F = max(1, in_flight)
+    y0, rows, stride = rdist.rank_rows(H, world, rank, 8)
+    n_groups = (H + 7) // 8
+    per_rank = (n_groups + world - 1) // world
+    most = per_rank * 8                                  # rows of the busiest rank: what every rank sends
+    streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
+    handles = [ds.clone(stream=st.cuda_stream) for st in streams]
+    for h in handles:
+        h.set_async(True)
+    packed = [torch.zeros((most, W, 3), dtype=torch.float32, device=dev) for _ in range(F)]
+    shown = [torch.zeros((most, W, 3), dtype=torch.uint8, device=dev) for _ in range(F)]
+    gathered = [torch.zeros((world, most, W, 3), dtype=torch.uint8, device=comm_dev) if (world > 1 and rank == 0) else None
+                for _ in range(F)]
+    frame_buf = [torch.zeros((per_rank * world * 8, W, 3), dtype=torch.uint8, device=comm_dev) if (world > 1 and rank == 0) else None
+                 for _ in range(F)]
+    pending = [None] * F
+    tonemap = abi.TONEMAP_CBRT if kind == "path" else abi.TONEMAP_NONE
+
+    def place(k):
+        # frame row (j * world + r) * 8 + i  <-  rank r, packed row j * 8 + i
+        frame_buf[k].view(per_rank, world, 8, W, 3).copy_(gathered[k].view(world, per_rank, 8, W, 3).transpose(0, 1))
+
+    def step(f):
+        k = f % F
+        with torch.cuda.stream(streams[k]):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+                if rank == 0:
+                    place(k)
+            if rows:
+                handles[k].render_device(rd_for(f, abi.FLAG_OVERWRITE, (0, y0, W, rows), 8, stride), packed[k].data_ptr())
+                handles[k].present_device(packed[k].data_ptr(), W, rows, shown[k].data_ptr(), passes=1, tonemap=tonemap, flip=False)
+            if world > 1:
+                src = shown[k] if backend == "nccl" else shown[k].cpu()
+                pending[k] = dist.gather(src, list(gathered[k].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
+
+    def drain():
+        for k in range(F):
+            if pending[k] is not None:
+                with torch.cuda.stream(streams[k]):
+                    pending[k].wait()
+                    if rank == 0:
+                        place(k)
+                pending[k] = None
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for f in range(F):                                   # warm-up: every handle once
+        step(f)
+    drain()
+    for h in handles:
+        h.wait()
+    sync()
+    t0 = time.perf_counter()
+    for f in range(F, F + frames):
+        step(f)
+    drain()
+    rays = sum(h.wait().rays for h in handles)
+    sync()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(rays)], dtype=torch.float64, device=comm_dev)
+    if world > 1:
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        dt = mx[0].item()
+    for h in handles:
+        h.close()
+    if rank != 0:
+        return None
+    return {"frames_in_flight": F, "frames": frames, "ms_per_frame": round(dt / frames * 1e3, 3),
+            "Mrays_per_s": round(tt[1].item() / dt / 1e6, 1), "n_gpus": world,
+            "step": "frames of the sequence queued without waiting, frame f on stream f % frames_in_flight; per frame every rank "
+                    "renders and presents its interleaved rows" + (" and rank 0 gathers and places them" if world > 1 else "")}
 
 
 def cpu_baseline_frames(desc, rd_of_frame, first_frame, budget_s=10.0, max_frames=40):

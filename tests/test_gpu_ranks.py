@@ -38,5 +38,7 @@ def test_two_ranks_on_one_gpu_print_one_line_with_both_scalings(gpu):
         f = out["frame_16spp"][kind]
         assert f["n_gpus"] == 2 and f["scaling"] == "strong" and f["ms_per_frame"] > 0
         assert out["strong_scaling"][kind]["n_gpus"] == 2
+        assert f["pipelined"]["n_gpus"] == 2 and f["pipelined"]["frames_in_flight"] == 3 and f["pipelined"]["ms_per_frame"] > 0
+        assert out["strong_scaling"][kind]["pipelined_ms_per_frame"] == f["pipelined"]["ms_per_frame"]
     # the rays of the frames the two ranks rendered, summed: more than one rank's share of the steps
     assert out["rays_per_frame"] > 320 * 184
