@@ -243,6 +243,17 @@ RTX_DEV u32x16 scalar_load_64(const void* p)
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(uniform_address(p)));
     return v;
 }
+// two loads from one record in flight together (one wait instead of two)
+RTX_DEV void scalar_load_64_16(const void* p, u32x16& a, u32x4& b)
+{
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b) : "s"(uniform_address(p)));
+}
+RTX_DEV void scalar_load_32_16(const void* p, u32x8& a, u32x4& b)
+{
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b) : "s"(uniform_address(p)));
+}
 RTX_DEV double dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 // index of the first active lane, and whether all active lanes hold it
 RTX_DEV bool wave_uniform(uint32_t index, uint32_t& first)
@@ -258,8 +269,8 @@ RTX_DEV Box6 load_prim_box(const PrimBox* __restrict__ boxes, uint32_t shape, bo
     Box6 r;
     if (uniform) {
         const char* p = reinterpret_cast<const char*>(boxes + first);
-        const u32x8 a = scalar_load_32(p);
-        const u32x4 b = scalar_load_16(p + 32);
+        u32x8 a; u32x4 b;
+        scalar_load_32_16(p, a, b);
         r.mn = mk(dbl(a[0], a[1]), dbl(a[2], a[3]), dbl(a[4], a[5]));
         r.mx = mk(dbl(a[6], a[7]), dbl(b[0], b[1]), dbl(b[2], b[3]));
     } else {
@@ -718,8 +729,8 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 d3 ta, tb, tc;
                 uint32_t shape, info;
                 if (same_leaf) {
-                    const u32x16 a = scalar_load_64(uq);
-                    const u32x4 b = scalar_load_16(reinterpret_cast<const char*>(uq) + 64);
+                    u32x16 a; u32x4 b;
+                    scalar_load_64_16(uq, a, b);
                     ta = mk(dbl(a[0], a[1]), dbl(a[2], a[3]), dbl(a[4], a[5]));
                     tb = mk(dbl(a[6], a[7]), dbl(a[8], a[9]), dbl(a[10], a[11]));
                     tc = mk(dbl(a[12], a[13]), dbl(a[14], a[15]), dbl(b[0], b[1]));
