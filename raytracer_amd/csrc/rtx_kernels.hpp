@@ -657,6 +657,61 @@ constexpr uint32_t kCandTie = 0x80000000u;          // flag: another shape ties 
 // certified -- the winner is in no visited leaf, or two different primitives tie exactly
 // at the winning depth (their visit order would decide) -- and the caller then runs the
 // reference-order walk for that ray.  Both are rare.
+// Single-precision form of the child-box test of the BVH walk.  The tree only proposes (every
+// candidate is tested against its own FP64 shape box and certified against the KD walk), so a child
+// box may be entered needlessly but must never be refused when the FP64 test would enter it.
+// Per ray and axis: i = float(1/d), and the parameter of a plane p is t = p * i - o/d, one fused
+// multiply-add.  With i and o/d rounded to single precision and the result rounded once, the
+// computed t is within 2^-23 * |1/d| * (|p| + |o|) of the exact one; |p| <= scene_scale for every
+// box of the tree, so widening the interval by delta = 2^-22 * |1/d| * (scene_scale + |o|) on that
+// axis covers it with a factor two to spare (it amounts to growing every box by 2^-22 of the
+// scene's size).  delta is folded into the additive constant: `cn` for the plane the ray meets
+// first on the axis (the lower one when d > 0), `cf` for the other.  An axis with |1/d| > 2^60 or
+// |o/d| > 2^100 refuses nothing, and scenes whose coordinates leave the range in which all of this
+// stays finite (scene_scale > 2^100) are not walked this way at all.
+struct SlabF32 {
+    float ix, iy, iz;
+    float cnx, cny, cnz, cfx, cfy, cfz;
+    bool px, py, pz;                    // d > 0 on the axis: the lower plane is the near one
+};
+RTX_DEV float float_not_below(double x)
+{
+    float f = (float)x;
+    if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1u : 0xffffffffu));
+    return f;
+}
+RTX_DEV void slab_f32_axis(double o, double inv, float reach, float& i, float& cn, float& cf, bool& positive)
+{
+    positive = inv >= 0.0;
+    if (fabs(inv) <= 0x1p60 && fabs(o * inv) <= 0x1p100) {
+        i = (float)inv;
+        const float c = (float)(-(o * inv));
+        const float delta = 0x1p-22f * fabsf(i) * reach + 1e-30f;
+        cn = c - delta; cf = c + delta;
+    } else {
+        i = positive ? 1.0f : -1.0f;
+        cn = -__builtin_huge_valf(); cf = __builtin_huge_valf();
+    }
+}
+RTX_DEV SlabF32 make_slab_f32(const DScene& s, d3 o, d3 inv)
+{
+    SlabF32 f;
+    const float scale = float_not_below(s.scene_scale * 1.001);
+    slab_f32_axis(o.x, inv.x, scale + float_not_below(fabs(o.x)), f.ix, f.cnx, f.cfx, f.px);
+    slab_f32_axis(o.y, inv.y, scale + float_not_below(fabs(o.y)), f.iy, f.cny, f.cfy, f.py);
+    slab_f32_axis(o.z, inv.z, scale + float_not_below(fabs(o.z)), f.iz, f.cnz, f.cfz, f.pz);
+    return f;
+}
+// entry and exit parameter (widened) of the box [lo, hi]
+RTX_DEV void slab_f32(const SlabF32& f, float lox, float loy, float loz, float hix, float hiy, float hiz, float& tn, float& tf)
+{
+    const float nx = fmaf(f.px ? lox : hix, f.ix, f.cnx), fx = fmaf(f.px ? hix : lox, f.ix, f.cfx);
+    const float ny = fmaf(f.py ? loy : hiy, f.iy, f.cny), fy = fmaf(f.py ? hiy : loy, f.iy, f.cfy);
+    const float nz = fmaf(f.pz ? loz : hiz, f.iz, f.cnz), fz = fmaf(f.pz ? hiz : loz, f.iz, f.cfz);
+    tn = fmaxf(fmaxf(nx, ny), nz);
+    tf = fminf(fminf(fx, fy), fz);
+}
+
 template <bool COUNT, bool ANYHIT>
 RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* stack, int32_t& best_prim,
                             double& best_depth, Work<COUNT>& w)
@@ -664,23 +719,39 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     best_prim = -1;
     best_depth = kInf;
     if (s.bvh_root == kBvhEmpty) return true;
+    if (!(s.scene_scale <= 0x1p100)) return false;     // beyond the single-precision box test: the reference-order walk
     uint32_t best_shape = 0;
     bool tie = false;
     d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    const double abs_margin = 1e-9 * (s.scene_scale + __builtin_fmax(fabs(o.x), __builtin_fmax(fabs(o.y), fabs(o.z))));
+    // (recomputed where it is wanted rather than held in registers through the loop)
+    auto margin = [&]() {
+        double x = o.x;
+        asm volatile("" : "+v"(x));
+        return 1e-9 * (s.scene_scale + __builtin_fmax(fabs(x), __builtin_fmax(fabs(o.y), fabs(o.z))));
+    };
     // A child is skipped when the ray enters its box beyond `bound`: the best depth so far
     // (closest hit) or the light distance (any hit), with a margin.  Directions are unit
     // vectors, so the ray parameter is the distance from the origin up to rounding, every hit
     // point the reference computes lies on the ray and in its shape's box up to rounding, and
     // the margin (1e-7 relative + 1e-9 of the scene) is far above those errors.
-    double bound = kInf;
-    if constexpr (ANYHIT) bound = limit * (1.0 + 1e-7) + abs_margin;
+    const SlabF32 f32 = make_slab_f32(s, o, inv);
+    // the bound as the single-precision test uses it: not below the FP64 one
+    float bound32 = __builtin_huge_valf();
+    if constexpr (ANYHIT) bound32 = float_not_below(limit * (1.0 + 1e-7) + margin());
+    // 1/d in FP64 is wanted again only where a shape passes rayHit (its own box test) and by the
+    // certificate after the loop: it is recomputed there instead of being held in six registers
+    // through the loop (the empty asm keeps the compiler from hoisting the divisions back out)
+    auto reciprocal = [&]() {
+        double x = d.x, y = d.y, z = d.z;
+        asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+        return mk(1.0 / x, 1.0 / y, 1.0 / z);
+    };
     int sp = 0;
     int32_t node = s.bvh_root;
     bool done = false;
     while (!done) {
         if (node >= 0) {
-            double lmin, lmax, rmin, rmax;
+            float lmin, lmax, rmin, rmax;
             int32_t left, right;
             const int32_t first_node = __builtin_amdgcn_readfirstlane(node);
             if (__all(node == first_node)) {
@@ -688,22 +759,22 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 // through the scalar cache in one load, not through the vector memory pipeline, and
                 // the slab arithmetic takes its boxes straight from the scalar registers
                 const u32x16 v = scalar_load_64(s.bvh_nodes + first_node);
-                slab_finite(mk(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2])),
-                            mk(__uint_as_float(v[3]), __uint_as_float(v[4]), __uint_as_float(v[5])), o, inv, lmin, lmax);
-                slab_finite(mk(__uint_as_float(v[6]), __uint_as_float(v[7]), __uint_as_float(v[8])),
-                            mk(__uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11])), o, inv, rmin, rmax);
+                slab_f32(f32, __uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                         __uint_as_float(v[3]), __uint_as_float(v[4]), __uint_as_float(v[5]), lmin, lmax);
+                slab_f32(f32, __uint_as_float(v[6]), __uint_as_float(v[7]), __uint_as_float(v[8]),
+                         __uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11]), rmin, rmax);
                 left = (int32_t)v[12]; right = (int32_t)v[13];
             } else {
                 // one node = four 16-byte loads
                 const float4* n = reinterpret_cast<const float4*>(s.bvh_nodes + node);
                 const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-                slab_finite(mk(n0.x, n0.y, n0.z), mk(n0.w, n1.x, n1.y), o, inv, lmin, lmax);
-                slab_finite(mk(n1.z, n1.w, n2.x), mk(n2.y, n2.z, n2.w), o, inv, rmin, rmax);
+                slab_f32(f32, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lmin, lmax);
+                slab_f32(f32, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, rmin, rmax);
                 left = __float_as_int(n3.x); right = __float_as_int(n3.y);
             }
             if constexpr (COUNT) w.content += 2;
-            bool hl = lmin <= lmax && lmax >= 0.0 && !(lmin > bound);
-            bool hr = rmin <= rmax && rmax >= 0.0 && !(rmin > bound);
+            bool hl = lmin <= lmax && lmax >= 0.0f && !(lmin > bound32);
+            bool hr = rmin <= rmax && rmax >= 0.0f && !(rmin > bound32);
             if (hl && hr) {
                 bool left_first = lmin <= rmin;
                 stack[sp * kTraceBlock] = left_first ? right : left;
@@ -757,7 +828,7 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 if (ANYHIT ? !(depth <= limit) : !(depth <= best_depth)) continue;
                 double tmin, tmax;
                 const Box6 sb = load_prim_box(s.prim_box, shape, same_leaf, same_leaf ? (uint32_t)__builtin_amdgcn_readfirstlane((int)shape) : 0u);
-                slab_finite(sb.mn, sb.mx, o, inv, tmin, tmax);
+                slab_finite(sb.mn, sb.mx, o, reciprocal(), tmin, tmax);
                 if constexpr (COUNT) w.aabb++;
                 if (!(tmin <= tmax && tmax >= 0.0)) continue;
                 if constexpr (ANYHIT) {
@@ -765,7 +836,7 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 } else if (depth < best_depth) {
                     if constexpr (COUNT) w.accepted++;
                     best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; tie = false;
-                    bound = best_depth * (1.0 + 1e-7) + abs_margin;
+                    bound32 = float_not_below(best_depth * (1.0 + 1e-7) + margin());
                 } else if ((int32_t)rp != best_prim) {
                     tie = true;
                 }
@@ -777,8 +848,9 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     }
     if (best_prim < 0) return true;                 // no geometric candidate at all: the reference finds none either
     if (tie) return false;
+    inv = reciprocal();
     d3 at = o + (d * best_depth);
-    if (member_by_cell(s, best_shape, o, d, best_depth, abs_margin)) return true;
+    if (member_by_cell(s, best_shape, o, d, best_depth, margin())) return true;
     return member_through_point<COUNT>(s, best_shape, at, o, d, inv, w) ||
            first_visited_position<COUNT>(s, best_shape, o, d, inv, w) != kNoPosition;
 }
@@ -982,7 +1054,7 @@ RTX_DEV void pool_ray(const DScene& s, const CameraQueue& cam, uint32_t light_ra
 }
 
 template <bool COUNT, int MODE>
-__global__ void __launch_bounds__(kTraceBlock)
+__global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(5, 5)))
 k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__ oy, const double* __restrict__ oz,
              const double* __restrict__ dx, const double* __restrict__ dy, const double* __restrict__ dz,
              const double* __restrict__ limit, uint32_t n, const uint32_t* __restrict__ n_device, uint32_t seg,
@@ -1068,7 +1140,9 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
     bool exhausted = cur == end;
     uint32_t ray = 0;
     d3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv = mk(0, 0, 0);
-    double lim = kInf, abs_margin = 0.0, bound2 = kInf, best_depth = kInf;
+    double lim = kInf, abs_margin = 0.0, best_depth = kInf;
+    SlabF32 f32 = {};
+    float bound32 = __builtin_huge_valf();
     int32_t best_prim = -1, node = 0;
     (void)lim;
     uint32_t best_shape = 0;
@@ -1096,11 +1170,11 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
                     o = mk(ox[at], oy[at], oz[at]); d = mk(dx[ray], dy[ray], dz[ray]);
                     if constexpr (ANYHIT) lim = limit[ray];
                     inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-                    exact = isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
+                    exact = isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && isfinite(o.x) && isfinite(o.y) && isfinite(o.z) &&
+                            s.scene_scale <= 0x1p100;
                     abs_margin = 1e-9 * (s.scene_scale + __builtin_fmax(fabs(o.x), __builtin_fmax(fabs(o.y), fabs(o.z))));
-                    // closest hit: squared distance bound; any hit: the light distance itself,
-                    // compared with the largest per-axis gap
-                    bound2 = ANYHIT ? lim * (1.0 + 1e-7) + abs_margin : kInf;
+                    f32 = make_slab_f32(s, o, inv);
+                    bound32 = ANYHIT ? float_not_below(lim * (1.0 + 1e-7) + abs_margin) : __builtin_huge_valf();
                     best_prim = -1; best_depth = kInf; best_shape = 0; tie = false;
                     sp = 0; node = s.bvh_root; leaf_k = 0;
                     pending = true;
@@ -1118,14 +1192,12 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
                 // one node = four 16-byte loads
                 const float4* nd = reinterpret_cast<const float4*>(s.bvh_nodes + node);
                 const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-                const d3 lb0 = mk(n0.x, n0.y, n0.z), lb1 = mk(n0.w, n1.x, n1.y);
-                const d3 rb0 = mk(n1.z, n1.w, n2.x), rb1 = mk(n2.y, n2.z, n2.w);
-                double lmin, lmax, rmin, rmax;
-                slab_finite(lb0, lb1, o, inv, lmin, lmax);
-                slab_finite(rb0, rb1, o, inv, rmin, rmax);
+                float lmin, lmax, rmin, rmax;
+                slab_f32(f32, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lmin, lmax);
+                slab_f32(f32, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, rmin, rmax);
                 if constexpr (COUNT) w.content += 2;
-                const bool hl = lmin <= lmax && lmax >= 0.0 && !(lmin > bound2);
-                const bool hr = rmin <= rmax && rmax >= 0.0 && !(rmin > bound2);
+                const bool hl = lmin <= lmax && lmax >= 0.0f && !(lmin > bound32);
+                const bool hr = rmin <= rmax && rmax >= 0.0f && !(rmin > bound32);
                 const int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
                 if (hl && hr) {
                     const bool left_first = lmin <= rmin;
@@ -1173,7 +1245,7 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
                     } else if (depth < best_depth) {
                         if constexpr (COUNT) w.accepted++;
                         best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; tie = false;
-                        bound2 = best_depth * (1.0 + 1e-7) + abs_margin;
+                        bound32 = float_not_below(best_depth * (1.0 + 1e-7) + abs_margin);
                     } else if ((int32_t)rp != best_prim) {
                         tie = true;
                     }
