@@ -680,13 +680,15 @@ RTX_DEV float float_not_below(double x)
     if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1u : 0xffffffffu));
     return f;
 }
-RTX_DEV void slab_f32_axis(double o, double inv, float reach, float& i, float& cn, float& cf, bool& positive)
+RTX_DEV void slab_f32_axis(double o, double inv, float scale, float& i, float& cn, float& cf, bool& positive)
 {
+    const double oi = o * inv;
     positive = inv >= 0.0;
-    if (fabs(inv) <= 0x1p60 && fabs(o * inv) <= 0x1p100) {
+    if (fabs(inv) <= 0x1p60 && fabs(oi) <= 0x1p100) {
         i = (float)inv;
-        const float c = (float)(-(o * inv));
-        const float delta = 0x1p-22f * fabsf(i) * reach + 1e-30f;
+        const float c = (float)(-oi);
+        // |1/d| * (scene_scale + |o|) = |1/d| * scene_scale + |o/d|, from the rounded values at hand
+        const float delta = 0x1p-22f * (fmaf(fabsf(i), scale, fabsf(c)) * 1.000001f) + 1e-30f;
         cn = c - delta; cf = c + delta;
     } else {
         i = positive ? 1.0f : -1.0f;
@@ -697,9 +699,9 @@ RTX_DEV SlabF32 make_slab_f32(const DScene& s, d3 o, d3 inv)
 {
     SlabF32 f;
     const float scale = float_not_below(s.scene_scale * 1.001);
-    slab_f32_axis(o.x, inv.x, scale + float_not_below(fabs(o.x)), f.ix, f.cnx, f.cfx, f.px);
-    slab_f32_axis(o.y, inv.y, scale + float_not_below(fabs(o.y)), f.iy, f.cny, f.cfy, f.py);
-    slab_f32_axis(o.z, inv.z, scale + float_not_below(fabs(o.z)), f.iz, f.cnz, f.cfz, f.pz);
+    slab_f32_axis(o.x, inv.x, scale, f.ix, f.cnx, f.cfx, f.px);
+    slab_f32_axis(o.y, inv.y, scale, f.iy, f.cny, f.cfy, f.py);
+    slab_f32_axis(o.z, inv.z, scale, f.iz, f.cnz, f.cfz, f.pz);
     return f;
 }
 // entry and exit parameter (widened) of the box [lo, hi]
@@ -738,14 +740,6 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     // the bound as the single-precision test uses it: not below the FP64 one
     float bound32 = __builtin_huge_valf();
     if constexpr (ANYHIT) bound32 = float_not_below(limit * (1.0 + 1e-7) + margin());
-    // 1/d in FP64 is wanted again only where a shape passes rayHit (its own box test) and by the
-    // certificate after the loop: it is recomputed there instead of being held in six registers
-    // through the loop (the empty asm keeps the compiler from hoisting the divisions back out)
-    auto reciprocal = [&]() {
-        double x = d.x, y = d.y, z = d.z;
-        asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-        return mk(1.0 / x, 1.0 / y, 1.0 / z);
-    };
     int sp = 0;
     int32_t node = s.bvh_root;
     bool done = false;
@@ -828,7 +822,7 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 if (ANYHIT ? !(depth <= limit) : !(depth <= best_depth)) continue;
                 double tmin, tmax;
                 const Box6 sb = load_prim_box(s.prim_box, shape, same_leaf, same_leaf ? (uint32_t)__builtin_amdgcn_readfirstlane((int)shape) : 0u);
-                slab_finite(sb.mn, sb.mx, o, reciprocal(), tmin, tmax);
+                slab_finite(sb.mn, sb.mx, o, inv, tmin, tmax);
                 if constexpr (COUNT) w.aabb++;
                 if (!(tmin <= tmax && tmax >= 0.0)) continue;
                 if constexpr (ANYHIT) {
@@ -848,7 +842,6 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     }
     if (best_prim < 0) return true;                 // no geometric candidate at all: the reference finds none either
     if (tie) return false;
-    inv = reciprocal();
     d3 at = o + (d * best_depth);
     if (member_by_cell(s, best_shape, o, d, best_depth, margin())) return true;
     return member_through_point<COUNT>(s, best_shape, at, o, d, inv, w) ||

@@ -26,8 +26,8 @@ def slab_f32(lo, hi, o, inv, scale):
         if abs(inv[k]) <= 2.0 ** 60 and abs(o[k] * inv[k]) <= 2.0 ** 100:
             i = F(inv[k])
             c = F(-(o[k] * inv[k]))
-            reach = F(s + not_below(abs(o[k])))
-            delta = F(F(F(2.0 ** -22) * abs(i)) * reach) + F(1e-30)
+            reach = F(np.float64(abs(i)) * np.float64(s) + np.float64(abs(c)))       # one fused multiply-add
+            delta = F(F(2.0 ** -22) * F(reach * F(1.000001))) + F(1e-30)
             cn, cf = F(c - delta), F(c + delta)
         else:
             i = F(1.0 if inv[k] >= 0 else -1.0)
