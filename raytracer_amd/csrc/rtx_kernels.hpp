@@ -769,15 +769,18 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
             if constexpr (COUNT) w.content += 2;
             bool hl = lmin <= lmax && lmax >= 0.0f && !(lmin > bound32);
             bool hr = rmin <= rmax && rmax >= 0.0f && !(rmin > bound32);
-            if (hl && hr) {
-                bool left_first = lmin <= rmin;
+            // (written without branches except for the deferred child's store)
+            const bool both = hl && hr;
+            const bool left_first = lmin <= rmin;
+            const bool go_left = both ? left_first : hl;
+            if (both) {
                 stack[sp * kTraceBlock] = left_first ? right : left;
                 ++sp;
-                node = left_first ? left : right;
+            }
+            if (hl || hr) {
+                node = go_left ? left : right;
                 continue;
             }
-            if (hl) { node = left; continue; }
-            if (hr) { node = right; continue; }
         } else {
             const uint32_t code = (uint32_t)~node;
             const BvhPrim* q = s.bvh_prims + (code >> 3);
