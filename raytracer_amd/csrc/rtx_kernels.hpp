@@ -1732,7 +1732,7 @@ k_shade_whitted_a(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
 
 // second half: direct lighting from the shadow results, the gather's sum, blend, spawn children
 template <bool GATHER>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* __restrict__ n_device, ShadowQueue sq,
                   const uint32_t* hit_index, GatherQueue gq, RayQueue next, uint32_t* next_count, double* sample)
 {
