@@ -665,14 +665,15 @@ constexpr uint32_t kCandTie = 0x80000000u;          // flag: another shape ties 
 // computed t is within 2^-23 * |1/d| * (|p| + |o|) of the exact one; |p| <= scene_scale for every
 // box of the tree, so widening the interval by delta = 2^-22 * |1/d| * (scene_scale + |o|) on that
 // axis covers it with a factor two to spare (it amounts to growing every box by 2^-22 of the
-// scene's size).  delta is folded into the additive constant: `cn` for the plane the ray meets
-// first on the axis (the lower one when d > 0), `cf` for the other.  An axis with |1/d| > 2^60 or
-// |o/d| > 2^100 refuses nothing, and scenes whose coordinates leave the range in which all of this
-// stays finite (scene_scale > 2^100) are not walked this way at all.
+// scene's size).  delta is folded into the additive constants: the plane the ray meets first on
+// the axis (the lower one when d > 0) gets -o/d - delta, the other -o/d + delta; `a` is the constant
+// that goes with a box's lower plane and `b` the one that goes with its upper plane, so that
+// min / max of the two products are the widened entry and exit on the axis whatever the sign of d.
+// An axis with |1/d| > 2^60 or |o/d| > 2^100 refuses nothing, and scenes whose coordinates leave
+// the range in which all of this stays finite (scene_scale > 2^100) are not walked this way at all.
 struct SlabF32 {
     float ix, iy, iz;
-    float cnx, cny, cnz, cfx, cfy, cfz;
-    bool px, py, pz;                    // d > 0 on the axis: the lower plane is the near one
+    float ax, ay, az, bx, by, bz;
 };
 RTX_DEV float float_not_below(double x)
 {
@@ -680,10 +681,11 @@ RTX_DEV float float_not_below(double x)
     if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1u : 0xffffffffu));
     return f;
 }
-RTX_DEV void slab_f32_axis(double o, double inv, float scale, float& i, float& cn, float& cf, bool& positive)
+RTX_DEV void slab_f32_axis(double o, double inv, float scale, float& i, float& a, float& b)
 {
     const double oi = o * inv;
-    positive = inv >= 0.0;
+    const bool positive = inv >= 0.0;
+    float cn, cf;
     if (fabs(inv) <= 0x1p60 && fabs(oi) <= 0x1p100) {
         i = (float)inv;
         const float c = (float)(-oi);
@@ -694,24 +696,26 @@ RTX_DEV void slab_f32_axis(double o, double inv, float scale, float& i, float& c
         i = positive ? 1.0f : -1.0f;
         cn = -__builtin_huge_valf(); cf = __builtin_huge_valf();
     }
+    a = positive ? cn : cf;
+    b = positive ? cf : cn;
 }
 RTX_DEV SlabF32 make_slab_f32(const DScene& s, d3 o, d3 inv)
 {
     SlabF32 f;
     const float scale = float_not_below(s.scene_scale * 1.001);
-    slab_f32_axis(o.x, inv.x, scale, f.ix, f.cnx, f.cfx, f.px);
-    slab_f32_axis(o.y, inv.y, scale, f.iy, f.cny, f.cfy, f.py);
-    slab_f32_axis(o.z, inv.z, scale, f.iz, f.cnz, f.cfz, f.pz);
+    slab_f32_axis(o.x, inv.x, scale, f.ix, f.ax, f.bx);
+    slab_f32_axis(o.y, inv.y, scale, f.iy, f.ay, f.by);
+    slab_f32_axis(o.z, inv.z, scale, f.iz, f.az, f.bz);
     return f;
 }
 // entry and exit parameter (widened) of the box [lo, hi]
 RTX_DEV void slab_f32(const SlabF32& f, float lox, float loy, float loz, float hix, float hiy, float hiz, float& tn, float& tf)
 {
-    const float nx = fmaf(f.px ? lox : hix, f.ix, f.cnx), fx = fmaf(f.px ? hix : lox, f.ix, f.cfx);
-    const float ny = fmaf(f.py ? loy : hiy, f.iy, f.cny), fy = fmaf(f.py ? hiy : loy, f.iy, f.cfy);
-    const float nz = fmaf(f.pz ? loz : hiz, f.iz, f.cnz), fz = fmaf(f.pz ? hiz : loz, f.iz, f.cfz);
-    tn = fmaxf(fmaxf(nx, ny), nz);
-    tf = fminf(fminf(fx, fy), fz);
+    const float x0 = fmaf(lox, f.ix, f.ax), x1 = fmaf(hix, f.ix, f.bx);
+    const float y0 = fmaf(loy, f.iy, f.ay), y1 = fmaf(hiy, f.iy, f.by);
+    const float z0 = fmaf(loz, f.iz, f.az), z1 = fmaf(hiz, f.iz, f.bz);
+    tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
 }
 
 template <bool COUNT, bool ANYHIT>

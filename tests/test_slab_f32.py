@@ -32,10 +32,12 @@ def slab_f32(lo, hi, o, inv, scale):
         else:
             i = F(1.0 if inv[k] >= 0 else -1.0)
             cn, cf = F(-np.inf), F(np.inf)
-        near, far = (lo[k], hi[k]) if inv[k] >= 0 else (hi[k], lo[k])
-        fma = lambda p, a, b: F(np.float64(p) * np.float64(a) + np.float64(b))
-        tn = max(tn, fma(near, i, cn))
-        tf = min(tf, fma(far, i, cf))
+        # the constant that goes with the lower plane, and the one that goes with the upper plane
+        a, b = (cn, cf) if inv[k] >= 0 else (cf, cn)
+        fma = lambda p, m, c: F(np.float64(p) * np.float64(m) + np.float64(c))
+        t0, t1 = fma(lo[k], i, a), fma(hi[k], i, b)
+        tn = max(tn, min(t0, t1))
+        tf = min(tf, max(t0, t1))
     return tn, tf
 
 
