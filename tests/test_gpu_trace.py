@@ -212,7 +212,7 @@ def test_bvh_walk_falls_back_on_ties_only(gpu):
         assert np.array_equal(imgs["bvh"], imgs["ref"])
 
 
-def _degenerate_scene(offset):
+def _degenerate_scene(offset, scale=1.0):
     """Geometry chosen to sit on KD cell faces and split planes and to stress the culls'
     margins: axis-aligned quads on integer planes (their boxes are flat and coincide with
     split values), needle and zero-area triangles, shapes listed twice, a sphere touching
@@ -241,12 +241,12 @@ def _degenerate_scene(offset):
     tris += list(zero)
     small = rng.uniform(-4, 4, size=(300, 1, 3)) + rng.normal(scale=0.3, size=(300, 3, 3))
     tris += list(small) + list(small[:40])                      # forty shapes present twice
-    pos = np.array(tris) + np.asarray(offset)
+    pos = (np.array(tris) + np.asarray(offset)) * scale
     n = len(pos)
     nrm = np.tile([0.0, 1.0, 0.0], (n, 3, 1))
     uv = np.tile([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]], (n, 1, 1))
     scene.triangles(pos, nrm, uv, m)
-    scene.sphere(tuple(np.asarray(offset) + [1.0, 1.0, 3.0]), 1.0, m)      # touches the plane z = 4 and x = 2
+    scene.sphere(tuple((np.asarray(offset) + [1.0, 1.0, 3.0]) * scale), 1.0 * scale, m)      # touches the plane z = 4 and x = 2
     return scene
 
 
@@ -287,3 +287,36 @@ def test_degenerate_geometry_walks_match_reference(gpu, walk, offset):
             same = (g == w) | ((g != g) & (w != w)) if g.dtype.kind == "f" else g == w
             assert same.all(), f"{name} {key}: {np.count_nonzero(~same)} of {same.size} differ"
     assert (want["prim"] >= 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("case", ["huge scene", "tiny direction components", "far origins"])
+def test_bvh_walk_beyond_the_range_of_its_single_precision_box_test(gpu, case):
+    """The BVH walk tests child boxes in single precision with headroom checks: a scene whose
+    coordinates exceed 2^100 is not walked that way at all, an axis with |1/d| > 2^60 or |o/d| > 2^100
+    refuses no box.  In all three cases the walk must still report the reference-order walk's hit."""
+    rng = np.random.default_rng(77)
+    scale = 1e31 if case == "huge scene" else 1.0
+    scene = _degenerate_scene((0.0, 0.0, 0.0), scale)
+    desc = scene.frame(0.0)
+    o, d = _random_rays(rng, 20000, box=6.0)
+    if case == "tiny direction components":
+        # one or two components of 1e-19 .. 1e-30 next to a dominant one: |1/d| up to 1e30
+        d = rng.normal(size=(20000, 3)) * 10.0 ** rng.uniform(-30, -19, size=(20000, 1))
+        d[np.arange(20000), rng.integers(0, 3, 20000)] = rng.choice([-1.0, 1.0], 20000)
+    if case == "far origins":
+        # origins 1e25 .. 1e33 away, aimed at the scene: |o/d| beyond 2^100 on some axes
+        target = rng.uniform(-4, 4, size=(20000, 3))
+        o = target + rng.normal(size=(20000, 3)) * 10.0 ** rng.uniform(25, 33, size=(20000, 1))
+        d = target - o
+    o = o * scale
+    with gpu.DeviceScene(desc) as ds:
+        got = ds.trace_closest(o, d, flags=abi.FLAG_RENDER_WALK)
+        ref = ds.trace_closest(o, d)
+    want = orc.trace_closest(desc, o, d)
+    for key in ("prim", "depth"):
+        for name, res in (("reference-order", ref), ("bvh", got)):
+            g, w = res[key], want[key]
+            same = (g == w) | ((g != g) & (w != w)) if g.dtype.kind == "f" else g == w
+            assert same.all(), f"{case}: {name} {key}: {np.count_nonzero(~same)} of {same.size} differ"
+    if case != "far origins":
+        assert (want["prim"] >= 0).mean() > 0.2
