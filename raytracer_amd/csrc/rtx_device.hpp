@@ -219,6 +219,31 @@ RTX_DEV bool triangle_depth(d3 a, d3 b, d3 c, d3 o, d3 d, double& depth)
     return true;
 }
 
+// The same test, also saying on which side of the origin the hit lies.  Triangle::rayHit computes
+// no ray parameter (Triangle.cpp:8-72): a front-facing triangle behind the origin is a hit like any
+// other, with depth = its distance.  The sign of Moeller-Trumbore's parameter, dot(E2, q) / det with
+// det > 0, tells the two apart; it steers the KD certificate only (never a result), so it need not
+// be exact near zero.
+RTX_DEV bool triangle_depth_sided(d3 a, d3 b, d3 c, d3 o, d3 d, double& depth, bool& behind)
+{
+    d3 E1 = b - a, E2 = c - a;
+    d3 pvec = cross(d, E2);
+    double det = dot(E1, pvec);
+    if (det < 0.0) return false;
+    double inv = 1.0 / det;
+    d3 tvec = o - a;
+    double u = dot(tvec, pvec) * inv;
+    if (u < 0.0 || u > 1.0) return false;
+    d3 qvec = cross(tvec, E1);
+    double v = dot(d, qvec) * inv;
+    if (v < 0.0 || u + v > 1.0) return false;
+    double bx = 1.0 - (u + v);
+    d3 pos = ((a * bx) + (b * u)) + (c * v);
+    depth = distance3(pos, o);
+    behind = dot(E2, qvec) < 0.0;
+    return true;
+}
+
 // full record of a triangle hit (the ray is known to hit)
 RTX_DEV bool triangle_full(const DScene& s, uint32_t tri, d3 o, d3 d, Hit& h)
 {

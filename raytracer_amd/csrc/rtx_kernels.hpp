@@ -649,7 +649,31 @@ constexpr uint32_t kCandSettled = 0xffffffffu;      // nothing to verify: no geo
                                                     //   the ray was walked in reference order already
 constexpr uint32_t kCandReference = 0xfffffffeu;    // not walked (non-finite ray): take the reference-order walk
 constexpr uint32_t kCandTie = 0x80000000u;          // flag: another shape ties at the winning depth
+constexpr uint32_t kCandBehind = 0x40000000u;       // flag: the winning hit lies behind the ray's origin (triangle_depth_sided)
 // otherwise: the winning candidate's shape id.
+
+// The certificate of a walk's winner: shape `cand & 0xffffff...` hit at `depth`.  The proofs want a
+// point of the ray (parameter > 0) in a KD leaf that holds the shape.  For a hit in front of the origin
+// that is the hit point.  A hit BEHIND the origin is not on the ray the reference's walk follows;
+// but the shape's box test passed (it reaches in front of the origin) and the box holds the hit
+// point, so the ray is inside the box from the origin on, and every KD leaf whose cell the box
+// touches holds the shape: the point used is the middle of the ray's stretch inside the box.
+template <bool COUNT>
+RTX_DEV bool certify_winner(const DScene& s, uint32_t cand, d3 o, d3 d, d3 inv, double depth, double margin, Work<COUNT>& w)
+{
+    const uint32_t shape = cand & ~(kCandTie | kCandBehind);
+    double t = depth;
+    if (cand & kCandBehind) {
+        double tmin, tmax;
+        slab_finite(s.prim_box + shape, o, inv, tmin, tmax);
+        t = 0.5 * (__builtin_fmax(tmin, 0.0) + tmax);
+        if (!(t > 0.0)) t = depth;          // nothing in front of the origin to stand on: the proofs below decide
+    }
+    if (member_by_cell(s, shape, o, d, t, margin)) return true;
+    const d3 at = o + (d * t);
+    return member_through_point<COUNT>(s, shape, at, o, d, inv, w) ||
+           first_visited_position<COUNT>(s, shape, o, d, inv, w) != kNoPosition;
+}
 
 // Optimistic form: the BVH walk treats every geometric candidate as genuine, so its loop
 // holds no long divergent section; the winner is verified once, after the loop, when the
@@ -814,10 +838,10 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 uint32_t type = info & 3u, idx = info >> 2;
                 double depth = kInf;
                 uint32_t rp = shape;
-                bool ok;
+                bool ok, behind = false;
                 if (type == RTX_PRIM_TRIANGLE) {
                     if constexpr (COUNT) w.tri++;
-                    ok = triangle_depth(ta, tb, tc, o, d, depth);
+                    ok = triangle_depth_sided(ta, tb, tc, o, d, depth, behind);
                 } else if (type == RTX_PRIM_SPHERE) {
                     if constexpr (COUNT) w.sph++;
                     ok = sphere_t(ld3(s.sph_center + 3 * (size_t)idx), s.sph_r2[idx], o, d, depth);
@@ -833,10 +857,10 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 if constexpr (COUNT) w.aabb++;
                 if (!(tmin <= tmax && tmax >= 0.0)) continue;
                 if constexpr (ANYHIT) {
-                    best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; done = true; break;
+                    best_depth = depth; best_prim = (int32_t)rp; best_shape = shape | (behind ? kCandBehind : 0u); done = true; break;
                 } else if (depth < best_depth) {
                     if constexpr (COUNT) w.accepted++;
-                    best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; tie = false;
+                    best_depth = depth; best_prim = (int32_t)rp; best_shape = shape | (behind ? kCandBehind : 0u); tie = false;
                     bound32 = float_not_below(best_depth * (1.0 + 1e-7) + margin());
                 } else if ((int32_t)rp != best_prim) {
                     tie = true;
@@ -849,10 +873,7 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     }
     if (best_prim < 0) return true;                 // no geometric candidate at all: the reference finds none either
     if (tie) return false;
-    d3 at = o + (d * best_depth);
-    if (member_by_cell(s, best_shape, o, d, best_depth, margin())) return true;
-    return member_through_point<COUNT>(s, best_shape, at, o, d, inv, w) ||
-           first_visited_position<COUNT>(s, best_shape, o, d, inv, w) != kNoPosition;
+    return certify_winner<COUNT>(s, best_shape, o, d, inv, best_depth, margin(), w);
 }
 
 RTX_DEV bool culling_is_exact(d3 o, d3 d)
@@ -1223,10 +1244,10 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
                     const uint32_t type = info & 3u, idx = info >> 2;
                     double depth = kInf;
                     uint32_t rp = shape;
-                    bool hit;
+                    bool hit, behind = false;
                     if (type == RTX_PRIM_TRIANGLE) {
                         if constexpr (COUNT) w.tri++;
-                        hit = triangle_depth(ta, tb, tc, o, d, depth);
+                        hit = triangle_depth_sided(ta, tb, tc, o, d, depth, behind);
                     } else if (type == RTX_PRIM_SPHERE) {
                         if constexpr (COUNT) w.sph++;
                         hit = sphere_t(ld3(s.sph_center + 3 * (size_t)idx), s.sph_r2[idx], o, d, depth);
@@ -1241,10 +1262,10 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
                     if constexpr (COUNT) w.aabb++;
                     if (!(tmin <= tmax && tmax >= 0.0)) break;
                     if constexpr (ANYHIT) {
-                        best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; sp = 0; pop = true;
+                        best_depth = depth; best_prim = (int32_t)rp; best_shape = shape | (behind ? kCandBehind : 0u); sp = 0; pop = true;
                     } else if (depth < best_depth) {
                         if constexpr (COUNT) w.accepted++;
-                        best_depth = depth; best_prim = (int32_t)rp; best_shape = shape; tie = false;
+                        best_depth = depth; best_prim = (int32_t)rp; best_shape = shape | (behind ? kCandBehind : 0u); tie = false;
                         bound32 = float_not_below(best_depth * (1.0 + 1e-7) + abs_margin);
                     } else if ((int32_t)rp != best_prim) {
                         tie = true;
@@ -1287,16 +1308,10 @@ k_verify(DScene s, const double* __restrict__ ox, const double* __restrict__ oy,
     Work<COUNT> w;
     bool ok = false;
     if (c != kCandReference && !(c & kCandTie)) {
-        const uint32_t shape = c;
         const double depth = hit_depth[i];
         const d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
         const double abs_margin = 1e-9 * (s.scene_scale + __builtin_fmax(fabs(o.x), __builtin_fmax(fabs(o.y), fabs(o.z))));
-        ok = member_by_cell(s, shape, o, d, depth, abs_margin);
-        if (!ok) {
-            d3 at = o + (d * depth);
-            ok = member_through_point<COUNT>(s, shape, at, o, d, inv, w) ||
-                 first_visited_position<COUNT>(s, shape, o, d, inv, w) != kNoPosition;
-        }
+        ok = certify_winner<COUNT>(s, c, o, d, inv, depth, abs_margin, w);
     }
     if (!ok) {
         if constexpr (COUNT) w.fallback++;
