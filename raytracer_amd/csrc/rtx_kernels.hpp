@@ -561,9 +561,8 @@ RTX_DEV bool member_through_point(const DScene& s, uint32_t shape, d3 p, d3 o, d
 // KDTree.cpp:171-194 tests.  The leaf is located from the deepest node that covers all leaves
 // of the shape, so only a few levels are walked and only with (axis, value).
 // The point tried first is the hit point.  A hit point ON a face of its cell (a floor that
-// is the bottom of the scene box, geometry lying in a split plane) cannot pass; the ray
-// then reached it from inside the cell or not at all, so the second try is the point a
-// little earlier on the ray, as far back as the offending faces require.
+// is the bottom of the scene box, geometry lying in a split plane) cannot pass; the second
+// try is the point a little earlier on the ray, as far back as the offending faces require.
 // A `false` only means "not shown this way".
 RTX_DEV int32_t locate_leaf(const DScene& s, int32_t node, d3 p)
 {
@@ -625,14 +624,16 @@ RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 o, d3 d, double 
     const double ly = (c.mn.y + margin) - p.y, hy = p.y - (c.mx.y - margin);
     const double lz = (c.mn.z + margin) - p.z, hz = p.z - (c.mx.z - margin);
     if (lx <= 0.0 && hx <= 0.0 && ly <= 0.0 && hy <= 0.0 && lz <= 0.0 && hz <= 0.0) return leaf_holds(s, shape, leaf, shape_uniform, first_shape);
-    // step back along the ray: a face the point is too close to must be one the ray leaves through
+    // step back along the ray.  A face the ray leaves through is cleared by `margin`; a face it came in
+    // through is crossed again, by `margin` into the cell on its other side (geometry lying in a split
+    // plane is held by the leaves of both sides).  The point stepped to is checked like the first.
     double back = 0.0;
-    if (lx > 0.0) { if (!(d.x < 0.0)) return false; back = __builtin_fmax(back, (lx + margin) / -d.x); }
-    if (hx > 0.0) { if (!(d.x > 0.0)) return false; back = __builtin_fmax(back, (hx + margin) / d.x); }
-    if (ly > 0.0) { if (!(d.y < 0.0)) return false; back = __builtin_fmax(back, (ly + margin) / -d.y); }
-    if (hy > 0.0) { if (!(d.y > 0.0)) return false; back = __builtin_fmax(back, (hy + margin) / d.y); }
-    if (lz > 0.0) { if (!(d.z < 0.0)) return false; back = __builtin_fmax(back, (lz + margin) / -d.z); }
-    if (hz > 0.0) { if (!(d.z > 0.0)) return false; back = __builtin_fmax(back, (hz + margin) / d.z); }
+    if (lx > 0.0) { if (d.x == 0.0) return false; back = __builtin_fmax(back, (d.x < 0.0 ? lx + margin : 3.0 * margin - lx) / __builtin_fabs(d.x)); }
+    if (hx > 0.0) { if (d.x == 0.0) return false; back = __builtin_fmax(back, (d.x > 0.0 ? hx + margin : 3.0 * margin - hx) / __builtin_fabs(d.x)); }
+    if (ly > 0.0) { if (d.y == 0.0) return false; back = __builtin_fmax(back, (d.y < 0.0 ? ly + margin : 3.0 * margin - ly) / __builtin_fabs(d.y)); }
+    if (hy > 0.0) { if (d.y == 0.0) return false; back = __builtin_fmax(back, (d.y > 0.0 ? hy + margin : 3.0 * margin - hy) / __builtin_fabs(d.y)); }
+    if (lz > 0.0) { if (d.z == 0.0) return false; back = __builtin_fmax(back, (d.z < 0.0 ? lz + margin : 3.0 * margin - lz) / __builtin_fabs(d.z)); }
+    if (hz > 0.0) { if (d.z == 0.0) return false; back = __builtin_fmax(back, (d.z > 0.0 ? hz + margin : 3.0 * margin - hz) / __builtin_fabs(d.z)); }
     const double t2 = t - back;
     if (!(t2 > 0.0)) return false;
     p = o + (d * t2);
