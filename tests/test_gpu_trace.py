@@ -212,6 +212,30 @@ def test_bvh_walk_falls_back_on_ties_only(gpu):
         assert np.array_equal(imgs["bvh"], imgs["ref"])
 
 
+def test_bounce_rays_are_certified_without_walking_the_kd_tree(gpu):
+    """A bounce ray starts 1e-3 off the surface it left, and Triangle::rayHit (Triangle.cpp:8-72, no
+    t >= 0 test) reports front-facing triangles behind that origin as hits; their `origin + direction
+    * depth` is no point of the ray.  The membership certificate must still settle them from the leaf
+    cell alone: the KD-branch steps of its slow proofs stay a small fraction of the rays, and the image
+    equals the reference-order one."""
+    from raytracer_amd import host
+    scene = scenes.mesh_scene(ggx=True, mesh="teapot")[0]
+    scene.sphere((0.0, 10.0, 0.0), 2.0, scene.material("PlainWhiteTees", emission=(8.0, 8.0, 8.0)))
+    desc = scene.frame(0.0)
+    cam = host.make_camera((0.0, 0.5, 12.0), (0.0, 0.0, 0.0))
+    imgs = {}
+    with gpu.DeviceScene(desc) as ds:
+        for name, fl in (("bvh", 0), ("ref", abi.FLAG_REFERENCE_ORDER)):
+            rd = scenes.render_desc(240, 180, integrator=abi.INTEGRATOR_PATH, camera=cam, max_depth=4, bias=1e-3,
+                                    flags=fl | abi.FLAG_COUNTERS)
+            imgs[name], st = ds.render(rd)
+            if name == "bvh":
+                assert st.fallback_rays == 0
+                assert st.rays > 60000
+                assert st.branch_visits < 0.05 * st.rays, (st.branch_visits, st.rays)
+    assert np.array_equal(imgs["bvh"], imgs["ref"])
+
+
 def _degenerate_scene(offset, scale=1.0):
     """Geometry chosen to sit on KD cell faces and split planes and to stress the culls'
     margins: axis-aligned quads on integer planes (their boxes are flat and coincide with
