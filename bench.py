@@ -271,7 +271,7 @@ def main_workload(ctx):
     if args.store_light_rays:
         kflags |= abi.FLAG_STORE_LIGHT_RAYS
     stream = torch.cuda.current_stream().cuda_stream
-    ds = device.DeviceScene(desc, stream=stream)
+    ds = device.DeviceScene(desc, stream=stream, static=True)      # one scene, many frames: rtx_scene_create_static
     # handle k renders the frames with step % F == k on stream k
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(F - 1)]
     handles = [ds] + [ds.clone(stream=st.cuda_stream) for st in streams[1:]]
@@ -414,6 +414,7 @@ def main_workload(ctx):
                 "parallelism": (f"frames x{world}, {'RCCL' if backend == 'nccl' else backend} gather of the presented "
                                 "RGB8 frames to rank 0" if world > 1 else "single GPU"),
                 "step": "render (float framebuffer in HBM) + present (8-bit sRGB, flipped); frames queued asynchronously, one wait at the end",
+                "scene": "created once with rtx_scene_create_static, the camera moves",
                 "frames_in_flight": F,
             },
             "rays_per_frame": total_rays / frames,
@@ -453,7 +454,7 @@ def frame_16spp(ctx, kind):
         scene.sphere((0.0, 10.0, 0.0), 2.0, scene.material("PlainWhiteTees", emission=(8.0, 8.0, 8.0)))
     desc = scene.frame(0.0)
     stream = torch.cuda.current_stream().cuda_stream
-    ds = device.DeviceScene(desc, stream=stream)
+    ds = device.DeviceScene(desc, stream=stream, static=True)      # one scene, many frames: rtx_scene_create_static
     kflags = {"bvh": 0, "kd-culled": abi.FLAG_KD_CULLED, "reference": abi.FLAG_REFERENCE_ORDER}[args.walk]
 
     def rd_for(f, flags=0, tile=None, group=0, stride=0):

@@ -19,6 +19,7 @@
 #include <memory>
 #include <utility>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "rtx_kernels.hpp"
@@ -457,9 +458,9 @@ constexpr size_t kScratchHeader = 3 * 256;      // queue-length ring, work count
 
 // fn(lo, hi) over [0, n) in a few contiguous pieces, each on a thread of its own
 template <class F>
-static void in_pieces(uint32_t n, F fn)
+static void in_pieces(uint32_t n, F fn, uint32_t want_pieces = 0)
 {
-    const uint32_t pieces = n < (1u << 16) ? 1u : 4u;
+    const uint32_t pieces = want_pieces ? std::max(1u, std::min(want_pieces, n)) : (n < (1u << 16) ? 1u : 4u);
     std::vector<std::future<void>> rest;
     for (uint32_t k = 1; k < pieces; ++k)
         rest.push_back(std::async(std::launch::async, fn, (uint32_t)((uint64_t)n * k / pieces), (uint32_t)((uint64_t)n * (k + 1) / pieces)));
@@ -496,7 +497,11 @@ int rtx_init(int device)
     return static_scratch(cur, &scratch_ptr);
 }
 
-int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
+}  // extern "C"
+
+// rtx_scene_create and rtx_scene_create_static; settled: also work out which shapes' leaf lists are
+// complete (kLcaSure), which costs host time once and saves the device a search per hit
+static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
 {
     if (!out) return fail(RTX_ERR_INVALID, "null output handle");
     *out = nullptr;
@@ -692,29 +697,113 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
         kd_split[i].greater = branches[i].greater;
     }
     std::vector<int32_t> prim_lca(s->n_shapes, s->kd_root);
+    // A shape whose leaf list provably holds EVERY leaf below that node whose cell comes within
+    // hold_margin of the shape's box gets kLcaSure: a point of that box inside such a cell is then
+    // in a leaf of the shape, and the device need not search the list (member_by_cell).  The
+    // reference's builder hands a shape to every child its box reaches (KDTree.cpp:78-113), so its
+    // trees earn the mark throughout; a caller's own tree is taken at its word only where it checks out.
+    double shape_scale = 0.0;
+    for (const PrimBox& b : boxes)
+        for (int k = 0; k < 3; ++k) shape_scale = std::max(shape_scale, std::max(std::fabs(b.bmin[k]), std::fabs(b.bmax[k])));
+    const double hold_margin = kHoldMargin * shape_scale;
+    // (the check walks the tree once per shape, memory-bound on the host: 55 ms for 68 k shapes, 70 ms on
+    // top of a 0.12 s scene for 960 k -- more than a scene that is rebuilt for every frame earns back,
+    // so it is done for scenes the caller creates as static only)
+    const bool mark_sure = settled && hold_margin > 0.0 && std::isfinite(hold_margin);
+    struct Sub { int32_t node; PrimBox cell; };          // a subtree and the cell its root was handed
+    auto enter = [&](PrimBox& c, const Branch& b) {
+        for (int k = 0; k < 3; ++k) { c.bmin[k] = std::max(c.bmin[k], b.bmin[k]); c.bmax[k] = std::min(c.bmax[k], b.bmax[k]); }
+    };
+    // one step of the check of shape p: false when the subtree is a leaf the widened box touches
+    // that is missing from the shape's list; children that need a look go to `out`
+    auto look = [&](uint32_t p, const Sub& it, std::vector<Sub>& out) {
+        const PrimBox& sb = boxes[p];
+        for (int k = 0; k < 3; ++k)
+            if (!(sb.bmin[k] - hold_margin <= it.cell.bmax[k] && sb.bmax[k] + hold_margin >= it.cell.bmin[k])) return true;
+        const uint32_t* ids = prim_leaf_ids.data() + prim_leaf_first[p];
+        const uint32_t* end = prim_leaf_ids.data() + prim_leaf_first[p + 1];
+        if (it.node < 0) return std::binary_search(ids, end, (uint32_t)~it.node);
+        const Branch& b = branches[it.node];
+        // a subtree whose leaves are all in the list needs no descent
+        const uint32_t* in_lo = std::lower_bound(ids, end, leaf_lo[it.node]);
+        const uint32_t* in_hi = std::lower_bound(in_lo, end, b.leaf_hi);
+        if ((uint32_t)(in_hi - in_lo) == b.leaf_hi - leaf_lo[it.node]) return true;
+        Sub l{b.lesser, it.cell}, g{b.greater, it.cell};
+        enter(l.cell, b); enter(g.cell, b);
+        l.cell.bmax[b.axis] = std::min(l.cell.bmax[b.axis], b.value);
+        g.cell.bmin[b.axis] = std::max(g.cell.bmin[b.axis], b.value);
+        out.push_back(l); out.push_back(g);
+        return true;
+    };
+    auto look_through = [&](uint32_t p, std::vector<Sub>& st) {       // depth first, until st is empty
+        while (!st.empty()) {
+            const Sub it = st.back();
+            st.pop_back();
+            if (!look(p, it, st)) return false;
+        }
+        return true;
+    };
+    // shapes in very many leaves (a floor: a hundred thousand) are checked afterwards, each by all threads
+    constexpr uint32_t kLongList = 4096;
+    std::vector<std::pair<uint32_t, Sub>> long_lists;
+    std::mutex long_lists_lock;
     in_pieces(s->n_shapes, [&](uint32_t first, uint32_t last) {
+        std::vector<Sub> st;
         for (uint32_t p = first; p < last; ++p) {
             if (prim_leaf_first[p] == prim_leaf_first[p + 1]) continue;      // in no leaf: never looked up
-            const uint32_t lo = prim_leaf_ids[prim_leaf_first[p]], hi = prim_leaf_ids[prim_leaf_first[p + 1] - 1];
+            const uint32_t* ids = prim_leaf_ids.data() + prim_leaf_first[p];
+            const uint32_t n_ids = prim_leaf_first[p + 1] - prim_leaf_first[p];
+            const uint32_t lo = ids[0], hi = ids[n_ids - 1];
             int32_t node = s->kd_root;
+            PrimBox cell;
+            for (int k = 0; k < 3; ++k) { cell.bmin[k] = -big; cell.bmax[k] = big; }
             while (node >= 0) {
                 const Branch& b = branches[node];
-                if (hi < b.leaf_mid) node = b.lesser;
-                else if (lo >= b.leaf_mid) node = b.greater;
+                if (hi < b.leaf_mid) { enter(cell, b); cell.bmax[b.axis] = std::min(cell.bmax[b.axis], b.value); node = b.lesser; }
+                else if (lo >= b.leaf_mid) { enter(cell, b); cell.bmin[b.axis] = std::max(cell.bmin[b.axis], b.value); node = b.greater; }
                 else break;
             }
             prim_lca[p] = node;
+            if (node < 0 || !mark_sure) continue;
+            if (n_ids > kLongList) {
+                std::lock_guard<std::mutex> hold(long_lists_lock);
+                long_lists.push_back({p, Sub{node, cell}});
+                continue;
+            }
+            st.clear();
+            st.push_back(Sub{node, cell});
+            if (look_through(p, st)) prim_lca[p] = node | kLcaSure;
         }
-    });
+    }, mark_sure ? 12u : 0u);
+    for (const auto& [p, root] : long_lists) {
+        // breadth first until there are subtrees enough for every thread, then those side by side
+        std::vector<Sub> front{root}, next;
+        bool sure = true;
+        while (sure && !front.empty() && front.size() < 4096) {
+            next.clear();
+            for (const Sub& it : front) if (!look(p, it, next)) { sure = false; break; }
+            front.swap(next);
+        }
+        std::atomic<bool> ok{sure};
+        if (sure && !front.empty()) {
+            const uint32_t shape = p;
+            in_pieces((uint32_t)front.size(), [&](uint32_t first, uint32_t last) {
+                std::vector<Sub> st;
+                for (uint32_t k = first; k < last && ok.load(std::memory_order_relaxed); ++k) {
+                    st.clear();
+                    st.push_back(front[k]);
+                    if (!look_through(shape, st)) ok.store(false, std::memory_order_relaxed);
+                }
+            }, 8);
+        }
+        if (ok.load()) prim_lca[p] |= kLcaSure;
+    }
     lap("kd_split, prim_lca");
     bvh_done.get();
     lap("wait for the BVH");
     d.bvh_root = bvh.root;
     sc->bvh_depth = (uint32_t)bvh.depth;
-    double scale = 0.0;
-    for (const PrimBox& b : boxes)
-        for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(b.bmin[k]), std::fabs(b.bmax[k])));
-    d.scene_scale = scale;
+    d.scene_scale = shape_scale;
 
     lap("bvh_prims, scale");
     sc->buffers = std::make_shared<DeviceBuffers>();
@@ -762,6 +851,11 @@ int rtx_scene_create(const rtx_scene_desc* s, rtx_scene** out)
     *out = sc;
     return RTX_OK;
 }
+
+extern "C" {
+
+int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) { return scene_create(desc, out, false); }
+int rtx_scene_create_static(const rtx_scene_desc* desc, rtx_scene** out) { return scene_create(desc, out, true); }
 
 int rtx_scene_set_stream(rtx_scene* sc, void* hip_stream)
 {

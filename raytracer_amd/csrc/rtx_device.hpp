@@ -123,6 +123,11 @@ struct PrimBox { double bmin[3]; double bmax[3]; };   // 48 bytes
 // negative leaf code: decode with an arithmetic shift)
 struct KdSplit { double value; int32_t lesser_axis; int32_t greater; };
 constexpr uint32_t kKdMaxNodes = 1u << 29;
+// prim_lca[shape]: the deepest KD node that covers all leaves of the shape (a branch index or a
+// leaf code < 0).  kLcaSure on a branch index: every leaf below it whose cell comes within
+// kHoldMargin x scene_scale of the shape's box is known to hold the shape.
+constexpr int32_t kLcaSure = 1 << 30;
+constexpr double kHoldMargin = 1e-7;
 
 // Candidate-finding BVH over the shape boxes (built by the library, see rtx_bvh.hpp):
 // a node carries both children's boxes; child >= 0 is a node, < 0 is a leaf whose code

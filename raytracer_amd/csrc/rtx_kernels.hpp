@@ -615,7 +615,22 @@ RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 o, d3 d, double 
 {
     uint32_t first_shape;
     const bool shape_uniform = wave_uniform(shape, first_shape);
-    const int32_t lca = shape_uniform ? (int32_t)scalar_load_4(s.prim_lca + first_shape) : s.prim_lca[shape];
+    const int32_t lca_code = shape_uniform ? (int32_t)scalar_load_4(s.prim_lca + first_shape) : s.prim_lca[shape];
+    const int32_t lca = lca_code < 0 ? lca_code : (lca_code & ~kLcaSure);
+    // The leaf list need not be searched when the shape has one leaf only (the one located), or when
+    // every leaf whose cell comes within kHoldMargin of the shape's box is known to hold it (kLcaSure)
+    // and the point tried is seen to lie that close to the box: it is in the cell located, so the
+    // cell reaches the widened box.
+    const bool one_leaf = lca_code < 0, sure = !one_leaf && (lca_code & kLcaSure);
+    Box6 sb;
+    if (sure) sb = load_prim_box(s.prim_box, shape, shape_uniform, first_shape);
+    auto listed = [&](d3 q) {
+        if (one_leaf) return true;
+        if (!sure) return false;
+        const double e = 0.9 * kHoldMargin * s.scene_scale;
+        return q.x >= sb.mn.x - e && q.x <= sb.mx.x + e && q.y >= sb.mn.y - e && q.y <= sb.mx.y + e &&
+               q.z >= sb.mn.z - e && q.z <= sb.mx.z + e;
+    };
     d3 p = o + (d * t);
     uint32_t leaf = (uint32_t)~locate_leaf(s, lca, p);
     Box6 c = load_leaf_cell(s, leaf);
@@ -623,7 +638,7 @@ RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 o, d3 d, double 
     const double lx = (c.mn.x + margin) - p.x, hx = p.x - (c.mx.x - margin);
     const double ly = (c.mn.y + margin) - p.y, hy = p.y - (c.mx.y - margin);
     const double lz = (c.mn.z + margin) - p.z, hz = p.z - (c.mx.z - margin);
-    if (lx <= 0.0 && hx <= 0.0 && ly <= 0.0 && hy <= 0.0 && lz <= 0.0 && hz <= 0.0) return leaf_holds(s, shape, leaf, shape_uniform, first_shape);
+    if (lx <= 0.0 && hx <= 0.0 && ly <= 0.0 && hy <= 0.0 && lz <= 0.0 && hz <= 0.0) return listed(p) || leaf_holds(s, shape, leaf, shape_uniform, first_shape);
     // step back along the ray.  A face the ray leaves through is cleared by `margin`; a face it came in
     // through is crossed again, by `margin` into the cell on its other side (geometry lying in a split
     // plane is held by the leaves of both sides).  The point stepped to is checked like the first.
@@ -642,7 +657,7 @@ RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 o, d3 d, double 
     bool inside = p.x - margin >= c.mn.x && p.x + margin <= c.mx.x &&
                   p.y - margin >= c.mn.y && p.y + margin <= c.mx.y &&
                   p.z - margin >= c.mn.z && p.z + margin <= c.mx.z;
-    return inside && leaf_holds(s, shape, leaf, shape_uniform, first_shape);
+    return inside && (listed(p) || leaf_holds(s, shape, leaf, shape_uniform, first_shape));
 }
 
 // What a walk leaves for a separate verification pass (k_verify), per ray:

@@ -19,7 +19,7 @@ _lib = None
 PD = C.POINTER(C.c_double)
 
 # every symbol include/rtx.h declares
-EXPORTS = ["rtx_init", "rtx_device_count", "rtx_scene_create", "rtx_scene_set_stream", "rtx_scene_destroy",
+EXPORTS = ["rtx_init", "rtx_device_count", "rtx_scene_create", "rtx_scene_create_static", "rtx_scene_set_stream", "rtx_scene_destroy",
            "rtx_scene_set_async", "rtx_scene_wait", "rtx_scene_clone",
            "rtx_trace_closest", "rtx_render", "rtx_render_device", "rtx_render_device_noalloc", "rtx_present", "rtx_present_device", "rtx_uniform",
            "rtx_last_error"]
@@ -40,6 +40,7 @@ def lib():
     L = C.CDLL(HIP_LIB)
     L.rtx_init.argtypes = [C.c_int]
     L.rtx_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_void_p)]
+    L.rtx_scene_create_static.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_void_p)]
     L.rtx_scene_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.rtx_scene_destroy.argtypes = [C.c_void_p]
     L.rtx_scene_set_async.argtypes = [C.c_void_p, C.c_int]
@@ -78,11 +79,15 @@ def device_count():
 class DeviceScene:
     """One frame's scene resident in HBM (rtx_scene_create .. rtx_scene_destroy)."""
 
-    def __init__(self, desc, stream=None, _clone_of=None):
+    def __init__(self, desc, stream=None, static=False, _clone_of=None):
+        """static: rtx_scene_create_static -- for a scene rendered many times (more host time once,
+        a cheaper membership check per hit; same results)."""
         self._L = lib()
         h = C.c_void_p()
         if _clone_of is not None:
             _check(self._L.rtx_scene_clone(_clone_of._h, C.byref(h)))
+        elif static:
+            _check(self._L.rtx_scene_create_static(C.byref(desc), C.byref(h)))
         else:
             _check(self._L.rtx_scene_create(C.byref(desc), C.byref(h)))
         self._h = h

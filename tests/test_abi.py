@@ -54,6 +54,7 @@ def test_hip_library_loads_and_exports_every_declared_symbol():
 def test_error_paths_without_a_gpu():
     L = device.lib()
     assert L.rtx_scene_create(None, C.byref(C.c_void_p())) == abi.RTX_ERR_INVALID
+    assert L.rtx_scene_create_static(None, C.byref(C.c_void_p())) == abi.RTX_ERR_INVALID
     assert b"null" in L.rtx_last_error()
     bad = abi.SceneDesc()
     bad.abi_version = 99

@@ -120,7 +120,7 @@ def _scenes_for_walks():
 
 
 @pytest.mark.parametrize("name,make,t,box", list(_scenes_for_walks()), ids=[c[0] for c in _scenes_for_walks()])
-@pytest.mark.parametrize("walk", ["bvh", "kd_culled"])
+@pytest.mark.parametrize("walk", ["bvh", "bvh_static", "kd_culled"])
 def test_render_walks_find_the_reference_hit(gpu, name, make, t, box, walk):
     """The render path's walks (BVH candidates + membership verification; culled KD walk)
     must report exactly the hit the reference-order walk reports: same primitive id (ties
@@ -131,7 +131,7 @@ def test_render_walks_find_the_reference_hit(gpu, name, make, t, box, walk):
     rng = np.random.default_rng(5)
     o, d = _random_rays(rng, 60000, box=box)
     # rays that start on geometry (like shadow and bounce rays do)
-    with gpu.DeviceScene(desc) as ds:
+    with gpu.DeviceScene(desc, static=walk == "bvh_static") as ds:      # rtx_scene_create_static: list searches skipped
         first = ds.trace_closest(o, d)
         hit = first["prim"] >= 0
         o2 = first["position"][hit] + 1e-3 * first["normal"][hit]
@@ -224,7 +224,7 @@ def test_bounce_rays_are_certified_without_walking_the_kd_tree(gpu):
     desc = scene.frame(0.0)
     cam = host.make_camera((0.0, 0.5, 12.0), (0.0, 0.0, 0.0))
     imgs = {}
-    with gpu.DeviceScene(desc) as ds:
+    with gpu.DeviceScene(desc, static=True) as ds:
         for name, fl in (("bvh", 0), ("ref", abi.FLAG_REFERENCE_ORDER)):
             rd = scenes.render_desc(240, 180, integrator=abi.INTEGRATOR_PATH, camera=cam, max_depth=4, bias=1e-3,
                                     flags=fl | abi.FLAG_COUNTERS)
@@ -234,6 +234,43 @@ def test_bounce_rays_are_certified_without_walking_the_kd_tree(gpu):
                 assert st.rays > 60000
                 assert st.branch_visits < 0.05 * st.rays, (st.branch_visits, st.rays)
     assert np.array_equal(imgs["bvh"], imgs["ref"])
+
+
+def test_kd_tree_that_leaves_shapes_out_of_leaves_they_reach(gpu):
+    """The reference's builder lists a shape in every leaf its box reaches, and for a scene created
+    with rtx_scene_create_static the membership certificate skips the search of a shape's leaf list
+    where the library has checked exactly that.
+    A caller's tree need not be so: here a quarter of the leaves lose their last shape (the entry is
+    overwritten with a copy of the leaf's first), so hits inside those cells belong to no visited leaf
+    there.  The render walk must still report what the reference-order walk reports on this tree."""
+    import ctypes as C
+    scene = scenes.mesh_scene(slices=80, stacks=40)[0]
+    desc = scene.frame(0.0)
+    first = np.ctypeslib.as_array(desc.leaf_first, shape=(desc.n_leaves,))
+    count = np.ctypeslib.as_array(desc.leaf_count, shape=(desc.n_leaves,))
+    refs = np.ctypeslib.as_array(desc.leaf_refs, shape=(desc.n_leaf_refs,)).copy()
+    rng = np.random.default_rng(21)
+    cut = np.flatnonzero((count >= 2) & (rng.random(desc.n_leaves) < 0.25))
+    refs[first[cut] + count[cut] - 1] = refs[first[cut]]
+    assert cut.size > 100
+    thin = abi.SceneDesc()
+    C.memmove(C.byref(thin), C.byref(desc), C.sizeof(thin))
+    thin.leaf_refs = refs.ctypes.data_as(C.POINTER(C.c_uint32))
+    o, d = _random_rays(rng, 200000, box=4.0)
+    with gpu.DeviceScene(thin, static=True) as ds:
+        ref = ds.trace_closest(o, d)
+        hit = ref["prim"] >= 0
+        o2 = ref["position"][hit] + 1e-3 * ref["normal"][hit]
+        oo = np.vstack([o, o2])
+        dd = np.vstack([d, rng.normal(size=o2.shape)])
+        ref = ds.trace_closest(oo, dd)
+        got = ds.trace_closest(oo, dd, flags=abi.FLAG_RENDER_WALK)
+    with gpu.DeviceScene(desc) as ds:
+        whole = ds.trace_closest(oo, dd)
+    assert np.array_equal(got["prim"], ref["prim"]), f"{np.count_nonzero(got['prim'] != ref['prim'])} ids differ"
+    assert np.array_equal(got["depth"], ref["depth"])
+    # the cut must matter: some rays see another shape (or none) than with the whole tree
+    assert np.count_nonzero(whole["prim"] != ref["prim"]) > 20
 
 
 def _degenerate_scene(offset, scale=1.0):

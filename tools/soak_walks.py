@@ -5,7 +5,7 @@ per seed -- random, aimed from far away, nearly axis-parallel, grazing, leaving 
 and shadow rays do (where triangles behind the origin are hits, Triangle.cpp:8-72) -- over the backpack, teapot and
 procedural mesh scenes.  Prints the number of rays whose hit id or depth differ (must be 0).
 
-    python tools/soak_walks.py [seed]
+    python tools/soak_walks.py [seed [static]]      (static: scenes made with rtx_scene_create_static)
 """
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ total = bad = 0
 for mesh in ("backpack", "teapot", None):
     scene, _ = scenes.mesh_scene(ggx=True, square_light=True, mesh=mesh)
     desc = scene.frame(0.0)
-    with device.DeviceScene(desc) as ds:
+    with device.DeviceScene(desc, static=(len(sys.argv) > 2 and sys.argv[2] == "static")) as ds:
         surface = None
         for rep in range(5):
             n = 1_000_000
