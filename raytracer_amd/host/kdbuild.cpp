@@ -16,10 +16,13 @@
 //   * no KDNode objects, no per-leaf vectors, no shape -> id hash map;
 //   * the top levels build their lesser subtree on another thread; subtrees are built
 //     with local numbering and spliced in afterwards, so the result does not depend on
-//     the number of threads.
+//     the number of threads;
+//   * near the root, where a node's two sorts are the longest serial stretches of the build,
+//     each is itself cut into pieces sorted side by side and merged (sortWide).
 #include <algorithm>
 #include <future>
 #include <thread>
+#include <vector>
 
 #include "scene.hpp"
 
@@ -40,9 +43,37 @@ inline bool recLess(const Rec& a, const Rec& b) {
     return a.pos < b.pos;
 }
 
+// std::sort of [first, last) by recLess, `ways` pieces sorted side by side and merged pairwise (a
+// strict total order -- the positions are unique -- so the result is std::sort's whatever the pieces)
+void sortWide(std::vector<Rec>& rec, int ways) {
+    const size_t n = rec.size();
+    if (ways < 2 || n < (size_t(1) << 15)) { std::sort(rec.begin(), rec.end(), recLess); return; }
+    std::vector<size_t> cut(ways + 1);
+    for (int k = 0; k <= ways; ++k) cut[k] = n * (size_t)k / (size_t)ways;
+    Rec* base = rec.data();
+    std::vector<std::future<void>> jobs;
+    for (int k = 1; k < ways; ++k)
+        jobs.push_back(std::async(std::launch::async, [=]() { std::sort(base + cut[k], base + cut[k + 1], recLess); }));
+    std::sort(base, base + cut[1], recLess);
+    for (auto& j : jobs) j.get();
+    for (int width = 1; width < ways; width *= 2) {
+        jobs.clear();
+        for (int k = 0; k + width < ways; k += 2 * width) {
+            Rec *a = base + cut[k], *b = base + cut[k + width], *c = base + cut[std::min(k + 2 * width, ways)];
+            jobs.push_back(std::async(std::launch::async, [=]() { std::inplace_merge(a, b, c, recLess); }));
+        }
+        for (auto& j : jobs) j.get();
+    }
+}
+
 struct Builder {
     const BoxTable& t;
     int spawnLayers;                        // layers (from the root) that may hand a subtree to another thread
+    int threads;
+
+    // threads a list of a node of this layer may use for its sort: the node's two lists and the
+    // subtrees beside it are at work at the same time
+    int sortWays(int layer) const { return layer < 8 ? std::max(1, threads >> (layer + 1)) : 1; }
 
     // returns the node id local to `out`: >= 0 branch, < 0 leaf ~id
     int32_t build(FlatKD& out, std::vector<uint32_t>&& ids, AABB box, int axis, int rwc, int layer) const {
@@ -61,7 +92,7 @@ struct Builder {
                 double m = t.mn[3 * (size_t)ids[i] + axis];
                 if (m <= value) rec.push_back({m, 0.0, (uint32_t)i, ids[i]});
             }
-            std::sort(rec.begin(), rec.end(), recLess);
+            sortWide(rec, sortWays(layer));
             lesserIds.resize(rec.size());
             for (size_t i = 0; i < rec.size(); ++i) lesserIds[i] = rec[i].id;
         };
@@ -79,7 +110,7 @@ struct Builder {
                 else if (!haveExtra || recLess(extra, r)) { extra = r; haveExtra = true; }
             }
             if (!rec.empty()) {
-                std::sort(rec.begin(), rec.end(), recLess);
+                sortWide(rec, sortWays(layer));
                 greaterIds.reserve(rec.size() + 1);
                 if (haveExtra) greaterIds.push_back(extra.id);
                 for (const Rec& r : rec) greaterIds.push_back(r.id);
@@ -183,7 +214,7 @@ void buildFlatKD(const std::vector<Shape*>& shapes, const AABB& box, FlatKD& out
         while ((1 << spawnLayers) < threads) ++spawnLayers;
         spawnLayers += 2;                   // more tasks than threads: subtrees differ in size
     }
-    Builder b{t, spawnLayers};
+    Builder b{t, spawnLayers, threads};
     out.root = b.build(out, std::move(ids), box, axis, recursionWithoutChange, layer);
     out.stats.branches = (uint32_t)out.value.size();
     out.stats.leaves = (uint32_t)out.leafFirst.size();
