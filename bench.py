@@ -23,10 +23,17 @@ bounces lit by an emissive sphere).  With N > 1 one frame is split over the rank
 rows (strong scaling) and the presented rows are gathered on rank 0.
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
-  roofline      the traversal kernel against the roof it is under (VALU issue), with the HBM and L2
-                figures beside it; counter-based entries come from profiles/counters.json, which names
-                the rocprofv3 run they were collected in
-  cpu_baseline  the CPU oracle timed on a bounded sample of the same workload
+  roofline        all kernels of a frame against the roof they are under: the SIMDs' vector-ALU time
+                  (the walk's nodes and shapes come out of L1 / L2 / Infinity Cache; HBM traffic is a few
+                  percent of the algorithmic bytes).  Counter-based entries come from profiles/counters.json,
+                  which names the rocprofv3 runs they were collected in (same frames as the timed ones
+                  when this script is run with the driver's --steps / --warmup)
+  cpu_baseline    the CPU oracle timed on a bounded sample of the same workload
+  latency         the same frames one at a time (one frame in flight)
+  reference_walk  the same frames walked node for node as the reference's traverseKDTree does
+                  (KDTree.cpp:158-220), with that walk's own algorithmic bytes per ray
+  frame_16spp     the two 1080p 16-spp frames of configs[3]
+  configs         configs[0], [2] and one frame of [4], one GPU
 """
 import argparse
 import json
@@ -45,8 +52,15 @@ L2_PEAK_GBS = 34500.0           # aggregate L2 bandwidth of the eight XCDs
 FP64_PEAK_TFLOPS = 78.6
 CLOCK_GHZ = 2.4
 SIMDS = 256 * 4
-# a wave64 VALU instruction occupies its SIMD (16 lanes wide) for four cycles
-VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / 4.0
+# The roof of these kernels: every SIMD's vector ALU busy every cycle.  SQ_ACTIVE_INST_VALU counts, per
+# wave, the quad-cycles its vector instructions occupy the SIMD's ALU (measured here: 4.1 cycles per
+# wave-instruction for this mix of FP64 and FP32 work; a SIMD runs one wave's vector instruction at a
+# time), so 4 x the counter summed over a frame's launches is SIMD-cycles of vector-ALU time, to be held
+# against SIMDS x clock x frame time.
+VALU_PEAK_GCYC = SIMDS * CLOCK_GHZ
+# the same roof in wave-instructions per second if every one took four cycles (FP64 and packed ones do,
+# plain FP32 ones take two once two waves share a SIMD): a reading aid, not the roof
+VALU_GINST_AT_4 = SIMDS * CLOCK_GHZ / 4.0
 
 TRACE_KERNELS = {
     "bvh": "k_trace_pool<false,3> (closest hit) and <false,4> (any hit): BVH candidates + KD membership verification",
@@ -71,32 +85,54 @@ def load_counters():
 
 
 def counter_figures(counters, workload, walk, ms_per_frame, dominant):
-    """Counter-based entries of a roofline block: VALU wave-instructions and HBM / L2 bytes per frame
-    (all kernels of a frame) against the frame time measured in THIS run, and the HBM traffic per launch
-    of the dominant kernel.  The counters were collected with kernels serialised by the profiler; the
-    instruction and byte counts of a frame do not depend on that, the time does not come from there."""
+    """Counter-based entries of a roofline block: vector-ALU time, VALU wave-instructions and HBM / L2
+    bytes per frame (all kernels of a frame) against the frame time measured in THIS run, and the HBM
+    traffic per launch of the dominant kernel.  The counters were collected with kernels serialised
+    by the profiler; the instruction and byte counts of a frame do not depend on that, the time does
+    not come from there."""
     if not counters or walk != "bvh":
         return None
     w = counters.get("workloads", {}).get(workload)
     if not w:
         return None
-    valu = hbm = l2 = lanes = 0.0
+    valu = busy = hbm = l2 = lanes = l2_hit = l2_all = tcp = tcp_miss = 0.0
     dom_traffic, dom_launches = 0.0, 0.0
+    per_kernel = {}
     for name, k in w["kernels"].items():
         per_frame = k["launches_per_frame"]
         valu += per_frame * k.get("SQ_INSTS_VALU", 0.0)
+        busy += per_frame * k.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0
         lanes += per_frame * k.get("SQ_THREAD_CYCLES_VALU", 0.0)
         bytes_ = (2.0 * k.get("FETCH_SIZE", 0.0) + k.get("WRITE_SIZE", 0.0)) * 1024.0
         hbm += per_frame * bytes_
         l2 += per_frame * k.get("TCC_REQ_sum", 0.0) * 128.0
+        l2_hit += per_frame * k.get("TCC_HIT_sum", 0.0)
+        l2_all += per_frame * (k.get("TCC_HIT_sum", 0.0) + k.get("TCC_MISS_sum", 0.0))
+        tcp += per_frame * k.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0)
+        tcp_miss += per_frame * k.get("TCP_TCC_READ_REQ_sum", 0.0)
         if any(d in name for d in dominant):
             dom_traffic += per_frame * bytes_
             dom_launches += per_frame
+        if k.get("SQ_INSTS_VALU", 0.0) > 1e5:
+            # the kernel's own figures from the profiled (serialised) launches: vector-ALU time over the
+            # launch's own cycles (GRBM_GUI_ACTIVE is summed over the eight XCDs), lanes, cache hit rates
+            cyc = k.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            hm = k.get("TCC_HIT_sum", 0.0) + k.get("TCC_MISS_sum", 0.0)
+            ta = k.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0)
+            per_kernel[name] = {
+                "launches_per_frame": round(per_frame, 2),
+                "valu_busy_alone": round(k.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (SIMDS * cyc), 3) if cyc else None,
+                "active_lane_frac": round(k.get("SQ_THREAD_CYCLES_VALU", 0.0) / (k["SQ_INSTS_VALU"] * 64.0), 3),
+                "l2_hit": round(k.get("TCC_HIT_sum", 0.0) / hm, 3) if hm else None,
+                "l1_hit": round(1.0 - k.get("TCP_TCC_READ_REQ_sum", 0.0) / ta, 3) if ta else None,
+                "hbm_bytes_per_launch": round(bytes_),
+            }
     s = ms_per_frame / 1e3
     out = {
+        "valu_busy_gcyc_per_s": round(busy / s / 1e9, 1),
+        "valu_busy": round(busy / s / 1e9 / VALU_PEAK_GCYC, 4),
         "valu_winst_per_frame": round(valu),
         "valu_ginst_per_s": round(valu / s / 1e9, 2),
-        "valu_frac": round(valu / s / 1e9 / VALU_PEAK_GINST, 4),
         "active_lane_frac": round(lanes / (valu * 64.0), 3) if valu else None,
         "hbm_bytes_per_frame": round(hbm),
         "hbm_gbs": round(hbm / s / 1e9, 1),
@@ -104,44 +140,44 @@ def counter_figures(counters, workload, walk, ms_per_frame, dominant):
         "l2_request_bytes_per_frame": round(l2),
         "l2_gbs": round(l2 / s / 1e9, 1),
         "l2_frac": round(l2 / s / 1e9 / L2_PEAK_GBS, 4),
+        "l2_hit": round(l2_hit / l2_all, 3) if l2_all else None,
+        "l1_hit": round(1.0 - tcp_miss / tcp, 3) if tcp else None,
         "traffic_per_launch": round(dom_traffic / dom_launches) if dom_launches else None,
+        "kernels": per_kernel,
+        "collected_on": w.get("bench_args"),
         "source": counters.get("source"),
     }
     return out
 
 
-def roofline_block(walk, alg_bytes, rays, ms_trav, launches, ms_per_frame, cf, serial=None, overlap=False, flops=None):
-    """The roofline object of one workload.  `bound` is VALU issue: the walk's nodes and shapes come
+def roofline_block(walk, alg_bytes, rays, ms_trav, launches, ms_per_frame, cf, overlap=False, flops=None):
+    """The roofline object of one workload.  `bound` is the vector ALU: the walk's nodes and shapes come
     out of L1 / L2 / Infinity Cache (HBM traffic is a few percent of the algorithmic bytes), and what a
-    frame's time buys is wave-level VALU instructions -- `achieved`, when the counters are at hand,
-    is those of ALL kernels of a frame over the frame time of this run, so frac <= 1 holds at step
-    level.  The HBM view the metric's definition asks for is kept under `hbm`: algorithmic bytes per
-    launch over the launch duration measured live with HIP events on the kernel's stream."""
+    frame's time buys is SIMD-cycles of vector-ALU work.  `achieved` = 4 x SQ_ACTIVE_INST_VALU of ALL
+    kernels of a frame (profiles/counters.json) over the frame time of this run, `peak` = every SIMD
+    busy at the nominal clock, so frac <= 1 holds at step level.  `traffic` = HBM bytes per launch of
+    the dominant kernel from the FETCH_SIZE / WRITE_SIZE passes.  The algorithmic bytes of the walk
+    (abi.algorithmic_bytes) are given per ray and per launch with the launch duration measured live
+    with HIP events on the kernel's stream; they are served from cache, so no fraction of the HBM
+    peak is made of them (hbm_frac under `counters` is what reaches HBM)."""
     avg_launch_s = (ms_trav / 1e3) / max(launches, 1)
-    bytes_per_launch = alg_bytes / max(launches, 1)
-    hbm_achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     r = {
-        "bound": "valu-issue",
-        "achieved": cf["valu_ginst_per_s"] if cf else None,
-        "peak": round(VALU_PEAK_GINST, 1),
-        "unit": "G wave-instructions/s",
-        "frac": cf["valu_frac"] if cf else None,
+        "bound": "valu",
+        "achieved": cf["valu_busy_gcyc_per_s"] if cf else None,
+        "peak": round(VALU_PEAK_GCYC, 1),
+        "unit": "G SIMD-cycles/s of vector-ALU time (1024 SIMDs x 2.4 GHz)",
+        "frac": cf["valu_busy"] if cf else None,
         "traffic": cf["traffic_per_launch"] if cf else None,
         "kernel": TRACE_KERNELS[walk],
         "avg_launch_ms": round(avg_launch_s * 1e3, 4),
         "launches": launches,
         "launches_overlap": overlap,
+        "algorithmic_bytes_per_ray": round(alg_bytes / max(rays, 1), 1),
+        "algorithmic_bytes_per_launch": round(alg_bytes / max(launches, 1)),
         "counters": cf,
-        "hbm": {
-            "bound": "hbm", "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(hbm_achieved / HBM_PEAK_GBS, 4),
-            "algorithmic_bytes_per_ray": round(alg_bytes / max(rays, 1), 1),
-            "algorithmic_bytes_per_launch": round(bytes_per_launch),
-            "note": "algorithmic bytes of the traversal launches / their HIP-event duration; the bytes are served from "
-                    "cache (counters.hbm_frac is what reaches HBM), so this is not the binding roof",
-            "serial": serial,
-        },
     }
+    if cf:
+        r["valu_winst_frac_if_4_cycles_each"] = round(cf["valu_ginst_per_s"] / VALU_GINST_AT_4, 4)
     if flops is not None and ms_trav > 0:
         r["fp64_valu_tflops"] = round(flops / (ms_trav / 1e3) / 1e12, 3)
         r["fp64_valu_frac"] = round(flops / (ms_trav / 1e3) / 1e12 / FP64_PEAK_TFLOPS, 4)
@@ -167,14 +203,17 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="further timed regions of --steps frames for the spread (the "
                                                            "first region is the reported one)")
     ap.add_argument("--frames16", type=int, default=10, help="frames timed per 16-spp workload")
+    ap.add_argument("--texture-size", type=int, default=4096,
+                    help="side of the mesh's albedo map in the 16-spp workloads (4096: the size of the map the reference binds "
+                         "to the backpack model, Models/backpack/1001_albedo.jpg; 256: the small checker of earlier rounds)")
     ap.add_argument("--frames16-in-flight", type=int, default=3,
                     help="frames of the 16-spp sequence kept in flight for the `pipelined` figure (0: leave it out)")
-    ap.add_argument("--only", choices=["all", "main", "f16w", "f16p"], default="all",
+    ap.add_argument("--only", choices=["all", "main", "f16w", "f16p", "c5"], default="all",
                     help="run one workload only (profiling runs)")
     ap.add_argument("--pmc-run", action="store_true",
-                    help="profiling run: only the warm-up and timed frames are rendered (no counting pass, serial leg, "
-                         "repeats or CPU baseline), so every launch the profiler sees belongs to one of warmup + steps "
-                         "(or 1 + frames16) frames")
+                    help="profiling run: only the timed frames are rendered, once (no warm-up frames, counting pass, "
+                         "one-at-a-time or reference-walk legs, repeats, other configs or CPU baseline), so every launch "
+                         "the profiler sees belongs to one of the --steps (or --frames16) frames a plain run times")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frame16", action="store_true", help="skip the 16-spp frames")
     ap.add_argument("--serial-chunks", action="store_true",
@@ -184,7 +223,11 @@ def main():
     ap.add_argument("--accumulate-samples", action="store_true", help="RTX_FLAG_ACCUMULATE_SAMPLES; same image, for comparison")
     ap.add_argument("--store-light-rays", action="store_true", help="RTX_FLAG_STORE_LIGHT_RAYS; same image, for comparison")
     ap.add_argument("--no-serial-leg", action="store_true",
-                    help="skip the untimed repeat of the frames with chunks one after the other (roofline.hbm.serial)")
+                    help="skip the legs that repeat the timed frames one at a time and with the reference's walk order "
+                         "(`latency`, `reference_walk`)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs[0] / [2] / [4] legs")
+    ap.add_argument("--c5-frames", type=int, default=1, help="frames of configs[4] (about 0.6 s of GPU time and 0.6 s of host "
+                                                             "preparation each, after 15 s to assemble the scene)")
     ap.add_argument("--walk", choices=["bvh", "kd-culled", "reference"], default="bvh",
                     help="bvh: candidates from the library's BVH, verified against the reference's KD walk "
                          "(default render path); kd-culled: the reference's KD tree walked with culling; "
@@ -194,6 +237,7 @@ def main():
     if args.pmc_run:
         args.no_cpu_baseline = True
         args.no_serial_leg = True
+        args.no_configs = True
         args.repeats = 0
 
     import torch
@@ -229,7 +273,7 @@ def main():
         out = main_workload(ctx)
     elif rank == 0:
         out = {"metric": "Mrays/s (primary+secondary+shadow closest-hit queries)", "only": args.only}
-    if not args.no_frame16 and args.only != "main":
+    if not args.no_frame16 and args.only not in ("main", "c5"):
         f16 = {}
         if args.only in ("all", "f16w"):
             f16["whitted_area_light"] = frame_16spp(ctx, "whitted")
@@ -240,9 +284,17 @@ def main():
             if world > 1:
                 # the scaling figure of the 16-spp metric: one frame over all ranks (strong scaling);
                 # `value` above is frames of a sequence dealt out to the ranks (weak scaling)
+                # one frame split over the ranks by rows (latency of ONE frame), the same with several frames in
+                # flight per rank, and the frames of the sequence dealt out to the ranks whole (frame f to
+                # rank f % N, Raytracer.cpp:595-752 is a frame loop): all three hold total work fixed
                 out["strong_scaling"] = {k: {"ms_per_frame": v["ms_per_frame"], "Mrays_per_s": v["Mrays_per_s"], "n_gpus": world,
-                                             "pipelined_ms_per_frame": (v.get("pipelined") or {}).get("ms_per_frame")}
+                                             "pipelined_ms_per_frame": (v.get("pipelined") or {}).get("ms_per_frame"),
+                                             "sequence_ms_per_frame": (v.get("sequence") or {}).get("ms_per_frame")}
                                          for k, v in f16.items()}
+    if args.only == "c5" and world == 1:
+        out["configs"] = other_configs(ctx, ("c5",))
+    elif args.only == "all" and not args.no_configs and world == 1:
+        out["configs"] = other_configs(ctx, ("c1", "c3", "c5"))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -324,7 +376,7 @@ def main_workload(ctx):
     # on the device and the stream orders render -> present -> gather); one wait ends the region.
     for h in handles:
         h.set_async(True)
-    for s in range(args.warmup):
+    for s in range(0 if args.pmc_run else args.warmup):
         step_fn(s, abi.FLAG_TRACE_TIMES)
     drain()
     for h in handles:
@@ -358,19 +410,60 @@ def main_workload(ctx):
     for h in handles:
         h.set_async(False)
 
-    # The same frames once more, untimed, with the two chunks one after the other: every traversal
-    # launch then has the machine to itself, which is what a per-launch bandwidth should be read on.
-    serial = None
-    if not (args.serial_chunks and F == 1) and not args.no_serial_leg:
-        s_ms, s_launches = 0.0, 0
+    # The same frames once more, one at a time: render + present, the host waits for each (two
+    # half-frame chunks on the library's two streams, which is what a single call does by default).
+    latency = reference_walk = None
+    if not args.no_serial_leg and world == 1:
+        def rd_alone(step):
+            rd1 = rd_for(step, abi.FLAG_OVERWRITE)
+            rd1.flags = (rd1.flags & ~abi.FLAG_SERIAL_CHUNKS) | (abi.FLAG_SERIAL_CHUNKS if args.serial_chunks else 0)
+            return rd1
+        ds.render_device(rd_alone(args.warmup), fb.data_ptr())          # the library's two lanes, should this be their first use
+        torch.cuda.synchronize()
+        l_rays = 0
+        t0 = time.perf_counter()
         for s in range(args.steps):
-            st = ds.render_device(rd_for(args.warmup + s, abi.FLAG_TRACE_TIMES | abi.FLAG_SERIAL_CHUNKS), fb.data_ptr())
-            s_ms += st.ms_traverse + st.ms_shadow
-            s_launches += st.traverse_launches
-        if s_ms > 0 and s_launches:
-            s_achieved = alg_bytes / (s_ms / 1e3) / 1e9
-            serial = {"achieved": round(s_achieved, 2), "frac": round(s_achieved / HBM_PEAK_GBS, 4),
-                      "avg_launch_ms": round(s_ms / s_launches, 4), "launches": s_launches}
+            l_rays += ds.render_device(rd_alone(args.warmup + s), fb.data_ptr()).rays
+            ds.present_device(fb.data_ptr(), W, H, shown[0].data_ptr(), passes=1, tonemap=abi.TONEMAP_NONE, flip=True)
+        torch.cuda.synchronize()
+        l_dt = time.perf_counter() - t0
+        latency = {"ms_per_frame": round(l_dt / args.steps * 1e3, 4), "Mrays_per_s": round(l_rays / l_dt / 1e6, 1),
+                   "frames": args.steps, "frames_in_flight": 1,
+                   "step": "the timed frames again, one at a time: rtx_render_device + rtx_present_device, the host waits for each"}
+        # The reference's own traversal work (traverseKDTree, KDTree.cpp:158-220: lesser then greater, no
+        # early exit, every leaf's shapes box-tested) on a few of the timed frames: what the GPU does
+        # with the walk the reference prescribes, with that walk's algorithmic bytes per ray.
+        if args.walk == "bvh":
+            n_ref = min(3, args.steps)
+            ref_flags = abi.FLAG_REFERENCE_ORDER | abi.FLAG_SERIAL_CHUNKS
+            r_bytes = r_rays = 0
+            for s in range(n_ref):
+                rdr = rd_for(args.warmup + s, abi.FLAG_COUNTERS)
+                rdr.flags = (rdr.flags & ~kflags) | ref_flags
+                st = ds.render_device(rdr, fb.data_ptr())
+                r_bytes += abi.algorithmic_bytes(st, "reference")
+                r_rays += st.rays
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r_ms = 0.0
+            for s in range(n_ref):
+                rdr = rd_for(args.warmup + s, abi.FLAG_TRACE_TIMES | abi.FLAG_OVERWRITE)
+                rdr.flags = (rdr.flags & ~kflags) | ref_flags
+                st = ds.render_device(rdr, fb.data_ptr())
+                r_ms += st.ms_traverse + st.ms_shadow
+            torch.cuda.synchronize()
+            r_dt = time.perf_counter() - t0
+            reference_walk = {
+                "Mrays_per_s": round(r_rays / r_dt / 1e6, 1), "ms_per_frame": round(r_dt / n_ref * 1e3, 3), "frames": n_ref,
+                "kernel": TRACE_KERNELS["reference"],
+                "traversal_ms_per_frame": round(r_ms / n_ref, 3),
+                "algorithmic_bytes_per_ray": round(r_bytes / max(r_rays, 1), 1),
+                "algorithmic_gbs": round(r_bytes / (r_ms / 1e3) / 1e9, 1) if r_ms > 0 else None,
+                "note": "algorithmic bytes = 72 B per branch visit + 8 per leaf + 52 per shape-box test + 72 per triangle / 32 per "
+                        "sphere test + 124 per accepted hit + 88 per ray, counted by the same kernel's counting build on these "
+                        "frames; the 20 MB tree is served from L2 / Infinity Cache, so the rate may exceed the HBM peak and is "
+                        "not held against it",
+            }
 
     tt = torch.tensor([elapsed, float(rays)] + spread, dtype=torch.float64, device=comm_dev)
     if world > 1:
@@ -424,9 +517,14 @@ def main_workload(ctx):
             "timed_region_ms": {"reported": round(elapsed * 1e3, 3), "repeats": len(regions),
                                 "min": round(regions[0] * 1e3, 3), "median": round(regions[len(regions) // 2] * 1e3, 3),
                                 "max": round(regions[-1] * 1e3, 3)},
-            "roofline": roofline_block(args.walk, alg_bytes, rays, ms_trav, launches, ms_per_step / world, cf, serial=serial,
+            "roofline": roofline_block(args.walk, alg_bytes, rays, ms_trav, launches, ms_per_step / world, cf,
                                        overlap=F > 1 or not args.serial_chunks, flops=flops),
         }
+        if latency is not None:
+            out["latency"] = latency
+            out["one_frame_at_a_time_ms"] = latency["ms_per_frame"]
+        if reference_walk is not None:
+            out["reference_walk"] = reference_walk
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_frames(desc, lambda f: rd_for(f, 0), args.warmup)
     for h in handles[1:]:
@@ -449,21 +547,16 @@ def frame_16spp(ctx, kind):
     W, H = args.width, args.height
     frames = max(1, args.frames16)
     mesh = None if args.mesh == "procedural" else args.mesh
-    scene, _ = scenes.mesh_scene(ggx=True, square_light=True, mesh=mesh)
-    if kind == "path":
-        scene.sphere((0.0, 10.0, 0.0), 2.0, scene.material("PlainWhiteTees", emission=(8.0, 8.0, 8.0)))
+    scene = scenes.frame16_scene("path" if kind == "path" else "whitted", mesh=mesh, texture_size=args.texture_size)
     desc = scene.frame(0.0)
     stream = torch.cuda.current_stream().cuda_stream
     ds = device.DeviceScene(desc, stream=stream, static=True)      # one scene, many frames: rtx_scene_create_static
     kflags = {"bvh": 0, "kd-culled": abi.FLAG_KD_CULLED, "reference": abi.FLAG_REFERENCE_ORDER}[args.walk]
+    if args.serial_chunks:
+        kflags |= abi.FLAG_SERIAL_CHUNKS
 
     def rd_for(f, flags=0, tile=None, group=0, stride=0):
-        cam = scenes.orbit_camera(f / 30.0)
-        if kind == "whitted":
-            return scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=4, light_n=2, max_depth=3,
-                                      bias=1e-2, frame=f, tile=tile, row_group=group, row_stride=stride, flags=flags | kflags)
-        return scenes.render_desc(W, H, integrator=abi.INTEGRATOR_PATH, camera=cam, n=4, max_depth=8, bias=1e-3, frame=f,
-                                  tile=tile, row_group=group, row_stride=stride, flags=flags | kflags)
+        return scenes.frame16_render_desc(kind, W, H, f, flags=flags | kflags, tile=tile, row_group=group, row_stride=stride)
 
     # Every rank renders its share of the frame -- the groups of 8 rows g with g % world == rank, one
     # tile of interleaved rows -- in ONE call (overwriting: no fill), presents its rows (8-bit sRGB)
@@ -501,7 +594,8 @@ def frame_16spp(ctx, kind):
         st = ds.render_device(rd_for(1, abi.FLAG_COUNTERS, (0, y0, W, rows), 8, stride), scratch.data_ptr())
         alg_bytes_frame, flops_frame, rays_frame = abi.algorithmic_bytes(st, args.walk), work_flops(st), st.rays
         del scratch
-    one_frame(0, abi.FLAG_TRACE_TIMES)
+    if not args.pmc_run:
+        one_frame(0, abi.FLAG_TRACE_TIMES)
     acc.update(rays=0, ms_trav=0.0, launches=0)
     sync()
     per_frame = []
@@ -519,9 +613,11 @@ def frame_16spp(ctx, kind):
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt = mx[0].item()
     total_rays = tt[1].item()
-    pipelined = None
+    pipelined = sequence = None
     if args.frames16_in_flight > 0 and not args.pmc_run:
-        pipelined = pipelined_frames(ctx, kind, ds, rd_for, frames, args.frames16_in_flight)
+        pipelined = pipelined_frames(ctx, kind, ds, rd_for, frames, args.frames16_in_flight, "rows")
+        if world > 1:
+            sequence = pipelined_frames(ctx, kind, ds, rd_for, frames, args.frames16_in_flight, "frames")
     out = None
     if rank == 0:
         ms_per_frame = dt / frames * 1e3
@@ -537,6 +633,9 @@ def frame_16spp(ctx, kind):
                          "configs[3] (pathTrace): the same mesh and floor, CookTorance/GGX Gp bounces, depth 8, lit by an "
                          "emissive sphere, 1080p 16 spp"),
             "mesh": args.mesh, "integrator": kind,
+            "albedo_texture": f"{args.texture_size} x {args.texture_size} RGB8 ({args.texture_size * args.texture_size * 3 >> 20} MiB), seeded "
+                              "procedural, addressed by the model's own uvs, nearest texel (Texture.cpp:39-55); the reference binds a "
+                              "4096 x 4096 map to this model (Models/backpack/1001_albedo.jpg, Model.cpp:91-94)",
             "ms_per_frame": round(ms_per_frame, 3),
             "ms_per_frame_min_median": [round(per_frame[0] * 1e3, 3), round(per_frame[len(per_frame) // 2] * 1e3, 3)],
             "Mrays_per_s": round(total_rays / dt / 1e6, 1),
@@ -547,25 +646,34 @@ def frame_16spp(ctx, kind):
                      "render (float framebuffer in HBM) + present (8-bit sRGB); one frame at a time, its two half-frame chunks "
                      "on the library's two streams"),
             "roofline": roofline_block(args.walk, alg_bytes_frame * scale, acc["rays"], acc["ms_trav"], acc["launches"],
-                                       ms_per_frame, cf, overlap=True, flops=flops_frame * scale),
+                                       ms_per_frame, cf, overlap=not args.serial_chunks, flops=flops_frame * scale),
         }
+        if cf:
+            out["active_lane_frac"] = cf["active_lane_frac"]
         if pipelined is not None:
             out["pipelined"] = pipelined
+        if sequence is not None:
+            out["sequence"] = sequence
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_rows(desc, lambda tile: rd_for(1, 0, tile), W, H)
     ds.close()
     return out
 
 
-def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight):
-    """The same frames as a sequence with `in_flight` of them queued at a time (frame f through a
-    handle cloned from the scene, on stream f % in_flight): every rank renders its interleaved rows of
-    each frame, presents them and rank 0 gathers the presented rows; nothing waits on the host until
-    the end.  A level of a pathTrace frame lasts at least as long as its longest ray's chain of
-    dependent steps however few rays it holds, so a rank's share of ONE frame does not shrink with
-    the number of ranks the way its ray count does; frames in flight fill those tails with the next
-    frames' work.  Returns, on rank 0, the time per frame over all ranks (max over ranks) and the
-    rate; the figure to compare across N."""
+def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight, partition):
+    """The same frames as a sequence with `in_flight` of them queued at a time on every rank (frame
+    through a handle cloned from the scene, each handle on a stream of its own, its chunks one
+    after the other: the other frames in flight fill its tails).  Two partitions over the ranks:
+      "rows"    every frame is split: a rank renders its interleaved groups of 8 rows, presents them and
+                rank 0 gathers and places the presented rows;
+      "frames"  the frames are dealt out whole, frame f to rank f % world (`frames` per rank, so
+                frames x world in all); a rank renders and presents its frame and rank 0 gathers the
+                presented frames.
+    A level of a pathTrace frame lasts at least as long as its longest ray's chain of dependent steps
+    however few rays it holds, so a rank's share of ONE frame does not shrink with the number of ranks
+    the way its ray count does; whole frames per rank do not have that floor.  Nothing waits on the
+    host until the end.  Returns, on rank 0, the time per frame over all ranks (max over ranks) and
+    the rate: the figures to compare across N."""
     import torch
     import torch.distributed as dist
     from raytracer_amd import abi
@@ -573,10 +681,14 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight):
     args, rank, world, dev, comm_dev, backend = (ctx[k] for k in ("args", "rank", "world", "dev", "comm_dev", "backend"))
     W, H = args.width, args.height
     F = max(1, in_flight)
-    y0, rows, stride = rdist.rank_rows(H, world, rank, 8)
-    n_groups = (H + 7) // 8
-    per_rank = (n_groups + world - 1) // world
-    most = per_rank * 8                                  # rows of the busiest rank: what every rank sends
+    by_rows = partition == "rows"
+    if by_rows:
+        y0, rows, stride = rdist.rank_rows(H, world, rank, 8)
+        n_groups = (H + 7) // 8
+        per_rank = (n_groups + world - 1) // world
+        most = per_rank * 8                              # rows of the busiest rank: what every rank sends
+    else:
+        y0, rows, stride, per_rank, most = 0, H, 0, 0, H
     streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
     handles = [ds.clone(stream=st.cuda_stream) for st in streams]
     for h in handles:
@@ -585,17 +697,20 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight):
     shown = [torch.zeros((most, W, 3), dtype=torch.uint8, device=dev) for _ in range(F)]
     gathered = [torch.zeros((world, most, W, 3), dtype=torch.uint8, device=comm_dev) if (world > 1 and rank == 0) else None
                 for _ in range(F)]
-    frame_buf = [torch.zeros((per_rank * world * 8, W, 3), dtype=torch.uint8, device=comm_dev) if (world > 1 and rank == 0) else None
-                 for _ in range(F)]
+    frame_buf = [torch.zeros((per_rank * world * 8, W, 3), dtype=torch.uint8, device=comm_dev)
+                 if (by_rows and world > 1 and rank == 0) else None for _ in range(F)]
     pending = [None] * F
     tonemap = abi.TONEMAP_CBRT if kind == "path" else abi.TONEMAP_NONE
 
     def place(k):
         # frame row (j * world + r) * 8 + i  <-  rank r, packed row j * 8 + i
-        frame_buf[k].view(per_rank, world, 8, W, 3).copy_(gathered[k].view(world, per_rank, 8, W, 3).transpose(0, 1))
+        if by_rows:
+            frame_buf[k].view(per_rank, world, 8, W, 3).copy_(gathered[k].view(world, per_rank, 8, W, 3).transpose(0, 1))
 
-    def step(f):
-        k = f % F
+    def step(j):
+        # the j-th step of this rank: frame j split by rows, or this rank's own frame j * world + rank
+        k = j % F
+        f = j if by_rows else j * world + rank
         with torch.cuda.stream(streams[k]):
             if pending[k] is not None:
                 pending[k].wait()
@@ -603,8 +718,11 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight):
                 if rank == 0:
                     place(k)
             if rows:
-                handles[k].render_device(rd_for(f, abi.FLAG_OVERWRITE, (0, y0, W, rows), 8, stride), packed[k].data_ptr())
-                handles[k].present_device(packed[k].data_ptr(), W, rows, shown[k].data_ptr(), passes=1, tonemap=tonemap, flip=False)
+                tile = (0, y0, W, rows)
+                rd = rd_for(f, abi.FLAG_OVERWRITE | abi.FLAG_SERIAL_CHUNKS, tile, 8 if by_rows else 0, stride)
+                handles[k].render_device(rd, packed[k].data_ptr())
+                handles[k].present_device(packed[k].data_ptr(), W, rows, shown[k].data_ptr(), passes=1, tonemap=tonemap,
+                                          flip=not by_rows)
             if world > 1:
                 src = shown[k] if backend == "nccl" else shown[k].cpu()
                 pending[k] = dist.gather(src, list(gathered[k].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
@@ -623,15 +741,15 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for f in range(F):                                   # warm-up: every handle once
-        step(f)
+    for j in range(F):                                   # warm-up: every handle once
+        step(j)
     drain()
     for h in handles:
         h.wait()
     sync()
     t0 = time.perf_counter()
-    for f in range(F, F + frames):
-        step(f)
+    for j in range(F, F + frames):
+        step(j)
     drain()
     rays = sum(h.wait().rays for h in handles)
     sync()
@@ -646,10 +764,192 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight):
         h.close()
     if rank != 0:
         return None
-    return {"frames_in_flight": F, "frames": frames, "ms_per_frame": round(dt / frames * 1e3, 3),
+    total_frames = frames if by_rows else frames * world
+    return {"partition": partition, "frames_in_flight": F, "frames": total_frames,
+            "ms_per_frame": round(dt / total_frames * 1e3, 3),
             "Mrays_per_s": round(tt[1].item() / dt / 1e6, 1), "n_gpus": world,
-            "step": "frames of the sequence queued without waiting, frame f on stream f % frames_in_flight; per frame every rank "
-                    "renders and presents its interleaved rows" + (" and rank 0 gathers and places them" if world > 1 else "")}
+            "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (HIP default)"),
+            "step": ("frames of the sequence queued without waiting, one stream per frame in flight; per frame every rank renders "
+                     "and presents its interleaved rows" + (" and rank 0 gathers and places them" if world > 1 else "")) if by_rows else
+                    ("frames of the sequence dealt out whole, frame f to rank f % N, queued without waiting on one stream per frame "
+                     "in flight; a rank renders and presents its frame and rank 0 gathers the presented frames")}
+
+
+def other_configs(ctx, which):
+    """BASELINE.json configs[0], [2] and [4] on one GPU, each a short leg of the default run:
+      c1  the classic Whitted scene (glass + mirror sphere, checker floor, one PointLight), 640x480, 1 spp,
+          depth 1 -- the configuration the reference's CPU path is quoted on; also timed on the CPU oracle;
+      c3  the same plus a Biconvex lens, mirror and copper spheres and an emissive sphere, pathTrace to
+          depth 8 with CookTorance shading, 1080p;
+      c5  ONE frame of the animated 4K sequence: sixteen 60 k-triangle meshes (960 k triangles), three
+          emissive spheres on circle0/1/2, pathTrace depth 8, 3840x2160 at 64 spp, with the host's
+          per-frame preparation (redoAABBs + buildKDTree + flatten, rtx_scene_create) timed beside it.
+    Each: frames one at a time (render + wait), and c1 / c3 also with four frames in flight."""
+    import torch
+    from raytracer_amd import abi, device, scenes
+    args, dev = ctx["args"], ctx["dev"]
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {}
+
+    def timed(ds, rd_of, frames, W, H, in_flight=0):
+        fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        ds.render_device(rd_of(0, abi.FLAG_OVERWRITE), fb.data_ptr())
+        torch.cuda.synchronize()
+        rays = 0
+        t0 = time.perf_counter()
+        for f in range(1, frames + 1):
+            rays += ds.render_device(rd_of(f, abi.FLAG_OVERWRITE), fb.data_ptr()).rays
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        r = {"ms_per_frame": round(dt / frames * 1e3, 4), "Mrays_per_s": round(rays / dt / 1e6, 1),
+             "rays_per_frame": round(rays / frames), "frames": frames, "finite": bool(torch.isfinite(fb).all().item())}
+        if in_flight > 1:
+            streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
+            clones = [ds.clone(stream=st.cuda_stream) for st in streams]
+            fbs = [torch.zeros_like(fb) for _ in range(in_flight)]
+            for c in clones:
+                c.set_async(True)
+
+            def queue(f):
+                k = f % in_flight
+                with torch.cuda.stream(streams[k]):
+                    clones[k].render_device(rd_of(f, abi.FLAG_OVERWRITE | abi.FLAG_SERIAL_CHUNKS), fbs[k].data_ptr())
+            for f in range(in_flight):
+                queue(f)
+            for c in clones:
+                c.wait()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for f in range(1, 4 * frames + 1):
+                queue(f)
+            q_rays = sum(c.wait().rays for c in clones)
+            torch.cuda.synchronize()
+            dtq = time.perf_counter() - t0
+            r["in_flight"] = {"frames_in_flight": in_flight, "frames": 4 * frames, "ms_per_frame": round(dtq / (4 * frames) * 1e3, 4),
+                              "Mrays_per_s": round(q_rays / dtq / 1e6, 1)}
+            for c in clones:
+                c.close()
+        return r
+
+    if "c1" in which:
+        out["c1"] = config1_leg(ctx, timed)
+    if "c3" in which:
+        out["c3"] = config3_leg(ctx, timed)
+    if "c5" in which and args.c5_frames > 0:
+        out["c5"] = config5_leg(ctx)
+    return out
+
+
+def config1_leg(ctx, timed):
+    import torch
+    from raytracer_amd import abi, device, scenes
+    args = ctx["args"]
+    stream = torch.cuda.current_stream().cuda_stream
+    scene, cam = scenes.whitted_scene()
+    desc = scene.frame(0.0)
+
+    def rd_c1(f, flags=0):
+        return scenes.render_desc(640, 480, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=1, max_depth=1, bias=1e-3, frame=f,
+                                  flags=flags)
+    with device.DeviceScene(desc, stream=stream, static=True) as ds:
+        c1 = timed(ds, rd_c1, 20, 640, 480, in_flight=4)
+    c1["workload"] = ("configs[0]: classic Whitted scene (glass + mirror sphere over a checker floor of two triangles, one PointLight), "
+                      "640x480, 1 spp, depth 1; rayTrace as the reference has it (refraction recurses, no mirror branch, "
+                      "Raytracer-Noah-Desktop.cpp:452-564)")
+    c1["kd_tree"] = scene.kd_stats()
+    if not args.no_cpu_baseline:
+        from oracle import binding as orc
+        t0 = time.perf_counter()
+        n, cpu_rays, threads = 0, 0, 1
+        while n < 50 and time.perf_counter() - t0 < 3.0:
+            _, _, st, threads = orc.render(desc, rd_c1(1 + n))
+            cpu_rays += st.rays
+            n += 1
+        dt = time.perf_counter() - t0
+        c1["cpu_baseline"] = {"value": round(cpu_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                              "ms_per_frame": round(dt / n * 1e3, 2), "sample": f"{n} whole frames ({cpu_rays} rays, {dt:.1f} s)"}
+    scene.close()
+    return c1
+
+
+def config3_leg(ctx, timed):
+    import torch
+    from raytracer_amd import abi, device, scenes
+    args = ctx["args"]
+    stream = torch.cuda.current_stream().cuda_stream
+    scene, cam = scenes.lens_scene()
+    desc = scene.frame(0.0)
+
+    def rd_c3(f, flags=0):
+        return scenes.render_desc(1920, 1080, integrator=abi.INTEGRATOR_PATH, camera=cam, n=1, max_depth=8, bias=1e-4, frame=f,
+                                  flags=flags)
+    with device.DeviceScene(desc, stream=stream, static=True) as ds:
+        c3 = timed(ds, rd_c3, 20, 1920, 1080, in_flight=4)
+    c3["workload"] = ("configs[2]: the Whitted scene plus a Biconvex lens, mirror and copper spheres, lit by an emissive sphere; "
+                      "pathTrace to depth 8 with CookTorance shading, 1080p, 1 spp")
+    if not args.no_cpu_baseline:
+        from oracle import binding as orc
+        t0 = time.perf_counter()
+        _, _, st, threads = orc.render(desc, rd_c3(1, 0))
+        dt = time.perf_counter() - t0
+        c3["cpu_baseline"] = {"value": round(st.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                              "ms_per_frame": round(dt * 1e3, 1), "sample": f"one whole frame ({st.rays} rays, {dt:.1f} s)"}
+    scene.close()
+    return c3
+
+
+def config5_leg(ctx):
+    """configs[4], one frame (or a few) of the sequence."""
+    import torch
+    from raytracer_amd import abi, device, scenes
+    args, dev = ctx["args"], ctx["dev"]
+    stream = torch.cuda.current_stream().cuda_stream
+    if True:
+        t0 = time.perf_counter()
+        scene = scenes.animated_scene(copies=16)
+        assemble_s = time.perf_counter() - t0
+        W5, H5 = 3840, 2160
+        fb = torch.zeros((H5, W5, 3), dtype=torch.float32, device=dev)
+        shown = torch.zeros((H5, W5, 3), dtype=torch.uint8, device=dev)
+        host_s = create_s = gpu_s = 0.0
+        rays = 0
+        tris = 0
+        # frame 0 warms the host's allocations and the device's workspaces (left out of a profiling run)
+        for f in range(1 if args.pmc_run else 0, args.c5_frames + 1):
+            t = (1 + f) / 30.0
+            t0 = time.perf_counter()
+            desc = scene.frame(t)                        # redoAABBs + buildKDTree + flatten (Raytracer.cpp:634-636)
+            t1 = time.perf_counter()
+            ds = device.DeviceScene(desc, stream=stream)    # rtx_scene_create: derived tables, candidate BVH, upload
+            t2 = time.perf_counter()
+            rd = scenes.render_desc(W5, H5, integrator=abi.INTEGRATOR_PATH, camera=scenes.orbit_camera(t, radius=30.0, height=6.0),
+                                    n=8, max_depth=8, bias=1e-3, frame=1 + f, flags=abi.FLAG_OVERWRITE)
+            st = ds.render_device(rd, fb.data_ptr())
+            ds.present_device(fb.data_ptr(), W5, H5, shown.data_ptr(), passes=1, tonemap=abi.TONEMAP_CBRT, flip=True)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            tris = desc.n_triangles
+            ds.close()
+            if f > 0:
+                host_s += t1 - t0; create_s += t2 - t1; gpu_s += t3 - t2; rays += st.rays
+        n = args.c5_frames
+        out = {
+            "workload": "configs[4]: one frame of the animated 4K sequence -- 16 seeded 60 k-triangle meshes + floor, three emissive spheres "
+                        "on circle0/1/2 (Animatable.cpp:22-35), pathTrace depth 8 with CookTorance, 3840x2160, 64 spp (n = 8), t = frame/30",
+            "triangles": tris, "kd_tree": scene.kd_stats(), "frames": n,
+            "ms_per_frame": round(gpu_s / n * 1e3, 1), "Mrays_per_s": round(rays / gpu_s / 1e6, 1), "rays_per_frame": round(rays / n),
+            "host_prepare_ms_per_frame": {"redoAABBs_buildKDTree_flatten": round(host_s / n * 1e3, 1), "rtx_scene_create": round(create_s / n * 1e3, 1),
+                                          "note": "per frame of an animated scene; raytracer_amd/sequence.py runs it on a worker thread while the "
+                                                  "previous frame renders"},
+            "scene_assembly_s_once": round(assemble_s, 1),
+            "finite": bool(torch.isfinite(fb).all().item()),
+            "cpu_baseline": None,
+            "cpu_baseline_note": "not timed: 530 M camera paths per frame are hours of CPU oracle time",
+            # the one configuration whose scene (about 1.2 GB) does not fit the 256 MB Infinity Cache
+            "counters": counter_figures(ctx["counters"], "c5", args.walk, gpu_s / n * 1e3, ("k_trace_pool<false, 3>",)),
+        }
+        scene.close()
+    return out
 
 
 def cpu_baseline_frames(desc, rd_of_frame, first_frame, budget_s=10.0, max_frames=40):

@@ -13,6 +13,12 @@
  * the calling thread's last failure is available from rtx_last_error().
  * Nothing here exits the process or throws (the reference printf+exit(-1)s,
  * e.g. Raytracer/SquareLight.cpp:80-90).
+ *
+ * Current device: every entry point that takes a scene makes the scene's
+ * device the calling thread's current HIP device (hipSetDevice) and leaves it
+ * so; rtx_init and rtx_scene_create* do the same with the device rtx_init
+ * chose.  A caller that drives several GPUs from one thread sets its own
+ * device again after a call.
  */
 #ifndef RTX_H
 #define RTX_H

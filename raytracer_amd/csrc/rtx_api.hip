@@ -750,7 +750,10 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
     in_pieces(s->n_shapes, [&](uint32_t first, uint32_t last) {
         std::vector<Sub> st;
         for (uint32_t p = first; p < last; ++p) {
-            if (prim_leaf_first[p] == prim_leaf_first[p + 1]) continue;      // in no leaf: never looked up
+            // in no leaf: the reference never tests the shape, and a candidate the BVH proposes on it
+            // must never be certified -- not even in a tree that is one leaf, where the root's code
+            // would read "the shape's one leaf"
+            if (prim_leaf_first[p] == prim_leaf_first[p + 1]) { prim_lca[p] = kLcaNone; continue; }
             const uint32_t* ids = prim_leaf_ids.data() + prim_leaf_first[p];
             const uint32_t n_ids = prim_leaf_first[p + 1] - prim_leaf_first[p];
             const uint32_t lo = ids[0], hi = ids[n_ids - 1];
@@ -861,11 +864,12 @@ int rtx_scene_set_stream(rtx_scene* sc, void* hip_stream)
 {
     if (!sc) return fail(RTX_ERR_INVALID, "null scene");
     hipStream_t next = static_cast<hipStream_t>(hip_stream);
-    if (next != sc->stream && sc->ws[0].counts) {
+    if (next != sc->stream) {
         // Ordering: everything a handle queues -- its lanes are forked from and joined to the scene's
-        // stream -- is ordered by that stream, and the handle's queues and counters are reused by
-        // the next call.  Work still running on the old stream would race with calls queued on the
-        // new one, so the old stream is drained before the switch.
+        // stream -- is ordered by that stream, and the handle's queues and counters (or, for
+        // rtx_render_device_noalloc, the device's static scratch array) are reused by the next call.
+        // Work still running on the old stream would race with calls queued on the new one, so the old
+        // stream is drained before the switch, whether or not this handle owns a workspace yet.
         USE_DEVICE(sc->device);
         HIP_TRY(hipStreamSynchronize(sc->stream));
     }
@@ -1082,6 +1086,7 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
     p.d = *rd;
     p.d.pixel_multisample_n = n;
     p.n = n;
+    p.band_stride = 1;
     const uint64_t padded_pixels = (uint64_t)rd->tile_w * rd->tile_h;     // every index is a pixel
     if (padded_pixels * n * n > 0xffffffffull) return fail(RTX_ERR_LIMIT, "more than 2^32 samples per pass in one tile");
     uint32_t nn = n * n;
@@ -1136,6 +1141,22 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
         uint64_t n_chunks = (padded_pixels + half - 1) / half;
         n_chunks += n_chunks & 1;
         pixels_per_chunk = std::max<uint64_t>(64, std::min(half, ((padded_pixels + n_chunks - 1) / n_chunks + 63) / 64 * 64));
+    }
+    // A tile that is exactly two chunks is dealt out in alternate bands of 8 rows (chunk k: bands k, k + 2,
+    // ...) instead of a lower and an upper half: the halves of a picture hold different amounts of
+    // geometry, and the lane with more of it then runs on alone at the end.  Pixels and their random
+    // streams are the same either way.  RTX_CHUNK_SPLIT=halves keeps contiguous halves.
+    bool alternate_bands = false;
+    uint64_t lane_pixels[2] = {0, 0};
+    if (!serial && (padded_pixels + pixels_per_chunk - 1) / pixels_per_chunk == 2) {
+        const uint32_t bands = (rd->tile_h + 7) / 8;
+        const char* env = std::getenv("RTX_CHUNK_SPLIT");
+        if (bands >= 2 && !(env && env[0] == 'h')) {
+            alternate_bands = true;
+            for (uint32_t b = 0; b < bands; ++b)
+                lane_pixels[b & 1] += (uint64_t)std::min<uint32_t>(8u, rd->tile_h - 8u * b) * rd->tile_w;
+            pixels_per_chunk = std::max(lane_pixels[0], lane_pixels[1]);
+        }
     }
     const int n_lanes = serial ? 1 : 2;
     const size_t cap = (size_t)pixels_per_chunk * nn;
@@ -1411,9 +1432,17 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
                 if (L.alive || next_t0 >= padded_pixels) continue;
                 L.p.pass = pass;
                 L.p.overwrite = ((rd->flags & RTX_FLAG_OVERWRITE) && pass == rd->first_pass) ? 1u : 0u;
-                L.p.chunk_t0 = (uint32_t)next_t0;
-                L.p.chunk_pixels = (uint32_t)std::min<uint64_t>(pixels_per_chunk, padded_pixels - next_t0);
-                next_t0 += L.p.chunk_pixels;
+                if (alternate_bands) {
+                    // lane k's one chunk of this pass: the tile's bands k, k + 2, ...
+                    L.p.band_stride = 2; L.p.band_first = (uint32_t)k;
+                    L.p.chunk_t0 = 0;
+                    L.p.chunk_pixels = (uint32_t)lane_pixels[k];
+                    next_t0 += k == 0 ? lane_pixels[0] : lane_pixels[1];
+                } else {
+                    L.p.chunk_t0 = (uint32_t)next_t0;
+                    L.p.chunk_pixels = (uint32_t)std::min<uint64_t>(pixels_per_chunk, padded_pixels - next_t0);
+                    next_t0 += L.p.chunk_pixels;
+                }
                 const size_t slots = (size_t)L.p.chunk_pixels * nn;
                 if (!camera_queue) {
                     L.timer_p->begin();

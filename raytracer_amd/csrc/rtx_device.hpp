@@ -128,6 +128,9 @@ constexpr uint32_t kKdMaxNodes = 1u << 29;
 // kHoldMargin x scene_scale of the shape's box is known to hold the shape.
 constexpr int32_t kLcaSure = 1 << 30;
 constexpr double kHoldMargin = 1e-7;
+// prim_lca of a shape that no leaf lists: the reference's walk never tests it, so no point of a ray
+// can certify it (the value is the code of a leaf no tree has: leaf ids stay below kKdMaxNodes)
+constexpr int32_t kLcaNone = INT32_MIN;
 
 // Candidate-finding BVH over the shape boxes (built by the library, see rtx_bvh.hpp):
 // a node carries both children's boxes; child >= 0 is a node, < 0 is a leaf whose code
@@ -548,8 +551,9 @@ RTX_DEV d3 cook_torrance(d3 vi, d3 vo, d3 vn, double smooth, d3 down, d3 F0, d3&
     double ndi = dot(vn, vi);
     double cosT = dot(vo, vn);
     double sinT = sqrt(1 - cosT * cosT);
-    // pow(b, 5.0) (CookTorrance.cpp:41) as four multiplications: within 2 units in the last place
-    // of the exact power, the same order as the device pow's own distance from the C library's
+    // pow(b, 5.0) (CookTorrance.cpp:41) as four multiplications: within 3 units in the last place
+    // of the C library's pow (relative 5.6e-16 at most; tests/test_oracle_kat.py bounds it), the same order
+    // as the device pow's own distance from it
     const double b1 = 1.0 - dot(vh, vi), b2 = b1 * b1;
     double p = (b2 * b2) * b1;
     d3 fres = F0 + (mk(1.0 - F0.x, 1.0 - F0.y, 1.0 - F0.z) * p);

@@ -79,6 +79,8 @@ struct RenderParams {
                                 //   thread that shades its hit or miss), so slots are stored, neither cleared
                                 //   nor read back.  2: as 1 with one sub-sample per pixel: the value goes
                                 //   straight into the framebuffer and no resolve launch follows
+    uint32_t band_stride;       // 1, or 2 when the tile's two chunks are its alternate bands of 8 rows: the chunk's
+    uint32_t band_first;        //   pixel index walks the bands band_first, band_first + band_stride, ... of the tile
     float* accum;               // the framebuffer (direct_store == 2)
     uint32_t light_rays_from_origin;    // 1: the scene's one light takes no random numbers (Point / Directional), so a
                                 //   light ray is a function of its origin: the shadow queue holds origins only and
@@ -616,6 +618,7 @@ RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 o, d3 d, double 
     uint32_t first_shape;
     const bool shape_uniform = wave_uniform(shape, first_shape);
     const int32_t lca_code = shape_uniform ? (int32_t)scalar_load_4(s.prim_lca + first_shape) : s.prim_lca[shape];
+    if (lca_code == kLcaNone) return false;     // in no leaf at all: the other proofs find its list empty and refuse it too
     const int32_t lca = lca_code < 0 ? lca_code : (lca_code & ~kLcaSure);
     // The leaf list need not be searched when the shape has one leaf only (the one located), or when
     // every leaf whose cell comes within kHoldMargin of the shape's box is known to hold it (kLcaSure)
@@ -936,8 +939,9 @@ RTX_DEV void add_static_efficiency(Counters, const Work<false>&) {}
 RTX_DEV void pixel_of(const RenderParams& p, uint32_t t, uint32_t& x, uint32_t& y)
 {
     const uint32_t W = p.d.tile_w, H = p.d.tile_h;
-    uint32_t band = t / (8u * W);
-    uint32_t r = t - band * 8u * W;
+    const uint32_t own_band = t / (8u * W);            // among the chunk's own bands (all full but possibly the tile's last)
+    uint32_t r = t - own_band * 8u * W;
+    const uint32_t band = own_band * p.band_stride + p.band_first;
     uint32_t hb = min(8u, H - 8u * band);
     uint32_t bx = r / (8u * hb);
     uint32_t r2 = r - bx * 8u * hb;

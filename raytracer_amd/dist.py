@@ -126,7 +126,11 @@ def render_frame_rows(render_rows, width, height, device, group=8, pg=None, comm
     rows on their rank and only ever needs the presented ones on rank 0).
     Rank 0 returns the assembled [height, width, 3] frame (row 0 = bottom row, as the renderer
     numbers them), the others None.  All buffers are kept between frames; rank 0 places the
-    gathered rows with ONE strided copy: rank r's k-th group is group r + k * world of the frame."""
+    gathered rows with ONE strided copy: rank r's k-th group is group r + k * world of the frame.
+
+    THE RETURNED TENSOR IS A VIEW OF ONE OF THOSE KEPT BUFFERS: it is valid until the next call of
+    this function in the process, which overwrites it.  A caller that keeps frames (a list of
+    frames, a writer that works behind the renderer) must `.clone()` what it keeps."""
     world = dist.get_world_size(pg) if dist.is_initialized() else 1
     rank = dist.get_rank(pg) if dist.is_initialized() else 0
     n_groups = (height + group - 1) // group

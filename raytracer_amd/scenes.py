@@ -146,6 +146,37 @@ def checker_texture(size=256, cells=8, seed=7):
     return np.clip(base + noise, 0, 255).astype(np.uint8)
 
 
+# the size of the backpack model's diffuse map (Raytracer/Models/backpack/1001_albedo.jpg: 4096 x 4096,
+# forced to three channels by loadTexture, Texture.cpp:9-27): 48 MB of texels
+ALBEDO_SIZE = 4096
+_albedo_cache = {}
+
+
+def albedo_texture(size=ALBEDO_SIZE, seed=7):
+    """Seeded RGB8 albedo map of the reference model's size: patches of a few hundred texels in
+    different base colours, a fine weave and per-texel noise on top, so that neighbouring texels
+    differ and a wrong texel shows.  The model's own map is a JPEG the image cannot ship as a
+    fixture at this size; what the sampler does (nearest texel, wrap, Texture.cpp:39-55) and
+    what it costs (one 3-byte read somewhere in 48 MB per hit) depend on the size and on the
+    model's uvs, not on the picture.  Cached per process."""
+    key = (size, seed)
+    if key not in _albedo_cache:
+        rng = np.random.default_rng(seed)
+        cells = max(1, size // 256)
+        palette = rng.integers(40, 216, size=(cells, cells, 3)).astype(np.int16)
+        img = np.repeat(np.repeat(palette, size // cells, axis=0), size // cells, axis=1)
+        if img.shape[0] != size:            # sizes that are no multiple of the patch count
+            img = np.pad(img, ((0, size - img.shape[0]), (0, size - img.shape[1]), (0, 0)), mode="edge")
+        i = np.arange(size, dtype=np.int16)
+        weave = ((i[:, None] // 4 + i[None, :] // 4) % 2) * 16 - 8
+        img += weave[..., None]
+        img += rng.integers(-12, 13, size=(size, size, 1), dtype=np.int16)
+        tex = np.clip(img, 0, 255).astype(np.uint8)
+        tex.setflags(write=False)
+        _albedo_cache[key] = tex
+    return _albedo_cache[key]
+
+
 _GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
@@ -162,16 +193,18 @@ def reference_mesh(name):
             np.ascontiguousarray(c[:, :, 6:8]).reshape(n, 6))
 
 
-def mesh_scene(slices=246, stacks=123, t=0.0, ggx=False, square_light=False, mesh=None):
+def mesh_scene(slices=246, stacks=123, t=0.0, ggx=False, square_light=False, mesh=None, texture_size=256):
     """Configs 2 and 4: a triangle mesh + floor.  Config 2: constant white material,
     DirectionalLight((-1,-1,-1)) (Raytracer-noah-laptop.cpp:608-611), orbit camera
     eye = (10 sin t, 0.1, 10 cos t) (:672).  Config 4 (ggx=True): smoothness/metalness
     > 0, albedo texture on the mesh, checker floor and (square_light) a 1x1 SquareLight
     at (0,10,0) facing down (Raytracer-Noah-Desktop.cpp:754).  `mesh` names a reference
-    model (reference_mesh) instead of the seeded procedural soup."""
+    model (reference_mesh) instead of the seeded procedural soup.  `texture_size`: side of the
+    albedo map; ALBEDO_SIZE (4096) is the size of the map the reference binds to the backpack
+    (Model.cpp:91-94), addressed by the model's own uvs; the default is a small checker."""
     s = HostScene()
     if ggx:
-        tex = s.texture(checker_texture())
+        tex = s.texture(checker_texture() if texture_size == 256 else albedo_texture(texture_size))
         mesh_mat = s.material_custom((1.0, 1.0, 1.0), ns=100.0, ni=1.0, transparency=0.0, metalness=0.5,
                                      smoothness=0.5, samplers={"color": (abi.SAMPLER_TEXTURE_VEC3, tex)})
         floor_mat = s.material("PlainWhiteTees", color_sampler=abi.SAMPLER_RY_CHECKERS)
@@ -187,6 +220,30 @@ def mesh_scene(slices=246, stacks=123, t=0.0, ggx=False, square_light=False, mes
         s.directional_light((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0))
     cam = make_camera((10.0 * np.sin(t), 0.1, 10.0 * np.cos(t)), (0.0, 0.0, 0.0))
     return s, cam
+
+
+def frame16_scene(kind, mesh="backpack", texture_size=ALBEDO_SIZE):
+    """The two 1080p 16-spp workloads of BASELINE.json configs[3], as bench.py times them and the
+    tests check them.  kind 'whitted': the mesh with GGX material parameters and its albedo map,
+    checker floor, one 1x1 SquareLight (rayTrace, soft shadows).  kind 'path': the same under
+    pathTrace, lit by an emissive sphere where the square light is (pathTrace knows no Light
+    objects, Raytracer.cpp:217-355)."""
+    scene, _ = mesh_scene(ggx=True, square_light=True, mesh=mesh, texture_size=texture_size)
+    if kind == "path":
+        scene.sphere((0.0, 10.0, 0.0), 2.0, scene.material("PlainWhiteTees", emission=(8.0, 8.0, 8.0)))
+    return scene
+
+
+def frame16_render_desc(kind, width, height, frame, flags=0, tile=None, row_group=0, row_stride=0, n=4, light_n=2):
+    """Render description of frame `frame` of those workloads: orbit camera at t = frame/30,
+    n x n sub-samples; rayTrace with light_n x light_n SquareLight samples per hit, or pathTrace
+    to depth 8."""
+    cam = orbit_camera(frame / 30.0)
+    if kind == "whitted":
+        return render_desc(width, height, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=n, light_n=light_n, max_depth=3,
+                           bias=1e-2, frame=frame, tile=tile, row_group=row_group, row_stride=row_stride, flags=flags)
+    return render_desc(width, height, integrator=abi.INTEGRATOR_PATH, camera=cam, n=n, max_depth=8, bias=1e-3, frame=frame,
+                       tile=tile, row_group=row_group, row_stride=row_stride, flags=flags)
 
 
 def lens_scene():

@@ -143,3 +143,21 @@ def test_band_partition_covers_the_frame_once():
                 seen[y0:y0 + h] += 1
         assert (seen == 1).all() and max(rows) - min(rows) <= 4
     assert len(rdist.band_rects(8, 3, 2, 0, bands_per_rank=4)) + len(rdist.band_rects(8, 3, 2, 1, bands_per_rank=4)) == 3
+
+
+def test_render_frame_rows_returns_a_view_that_the_next_call_overwrites():
+    """The frame render_frame_rows returns lives in a buffer kept between frames: a clone of the
+    first frame keeps its contents, the tensor returned first shows the second frame afterwards."""
+    from raytracer_amd import dist as rdist
+    value = [1.0]
+
+    def render_rows(y0, rows, group, stride, out):
+        out.fill_(value[0])
+    for height in (16, 21):                 # rows in frame order / rows placed through the gather buffers
+        value[0] = 1.0
+        first = rdist.render_frame_rows(render_rows, 4, height, torch.device("cpu"), group=8)
+        kept = first.clone()
+        value[0] = 2.0
+        second = rdist.render_frame_rows(render_rows, 4, height, torch.device("cpu"), group=8)
+        assert first.shape == (height, 4, 3) and torch.all(kept == 1.0) and torch.all(second == 2.0)
+        assert first.data_ptr() == second.data_ptr() and torch.all(first == 2.0)

@@ -142,6 +142,35 @@ def test_reference_fbx_model_on_the_hot_path(gpu, mesh, integrator):
         assert stats.rays_shadow > 0 and stats.fallback_rays <= stats.rays // 100
 
 
+@pytest.mark.parametrize("kind", ["whitted", "path"])
+def test_bench_16spp_scenes_reduced_against_the_oracle(gpu, kind):
+    """The two scenes bench.py times as BASELINE configs[3] -- the backpack model with GGX material
+    parameters and a 4096 x 4096 albedo map addressed by the model's uvs, checker floor, and either
+    the 1x1 SquareLight sampled 2x2 per hit under rayTrace (Raytracer-Noah-Desktop.cpp:479-498,754)
+    or an emissive sphere under pathTrace to depth 8 (Raytracer.cpp:217-355) -- at a size the CPU
+    oracle renders in seconds, frames of the bench's own camera orbit, 2x2 sub-samples: ray counts
+    equal, RGB within 1e-4 relative / 60 dB."""
+    scene = scenes.frame16_scene(kind)
+    desc = scene.frame(0.0)
+    assert desc.n_triangles == 67908 + 2 and desc.n_texel_bytes == 4096 * 4096 * 3
+    W, H = (176, 99) if kind == "whitted" else (144, 81)
+    with gpu.DeviceScene(desc, static=True) as ds:
+        for frame in (1, 23):
+            rd = scenes.frame16_render_desc(kind, W, H, frame, n=2, light_n=2)
+            img, stats = ds.render(rd)
+            ref, _, ref_stats, _ = orc.render(desc, rd)
+            _same_ray_counts(stats, ref_stats)
+            assert stats.rays_primary == W * H * 4
+            if kind == "whitted":
+                assert stats.rays_shadow % 4 == 0 and stats.rays_shadow > 0.3 * stats.rays_primary
+            else:
+                assert stats.rays_secondary > 0.3 * stats.rays_primary
+            _close(img, ref, multi_bounce=True)
+            assert img.max() > 0.05
+            # the albedo map must matter: the picture has many more colours than floor + light alone give
+            assert len(np.unique((ref * 255).astype(np.uint8).reshape(-1, 3), axis=0)) > 100
+
+
 def test_small_tiles_after_a_larger_render_on_the_same_handle(gpu):
     """Chunks with fewer sample slots than the ring of queue lengths has words (a 2x2 frame, a
     3x1 tile), rendered after a larger frame on the same handle, whose queue lengths are still in

@@ -470,14 +470,16 @@ def test_present_matches_oracle_and_writes_png(gpu, tmp_path):
         assert back.shape == (100, 160, 3) and back.max() > 50
 
 
-def test_full_size_bench_workload_properties(gpu):
-    """The bench workload at its full size (60 026 triangles, 1920x1080, Whitted + directional
-    light), where the CPU oracle would take minutes: size-independent properties instead.
+@pytest.mark.parametrize("mesh", ["backpack", None], ids=["backpack", "procedural"])
+def test_full_size_bench_workload_properties(gpu, mesh):
+    """The bench workload at its full size (the reference's backpack model, 67 908 triangles, or
+    the procedural 60 024-triangle mesh; 1920x1080, Whitted + directional light), where the CPU
+    oracle would take minutes: size-independent properties instead.
     The three walks must give the same image bit for bit and the same ray counts; four tiles
     rendered separately must compose to the whole frame; a second pass must add exactly the
     first pass's image again (no random numbers on this path)."""
     import torch
-    scene, _ = scenes.mesh_scene()
+    scene, _ = scenes.mesh_scene(mesh=mesh)
     desc = scene.frame(0.0)
     cam = scenes.orbit_camera(0.4)
     W, H = 1920, 1080
@@ -486,7 +488,7 @@ def test_full_size_bench_workload_properties(gpu):
         return scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=1, max_depth=3, bias=1e-2,
                                   clear=(0.21, 0.78, 0.95), flags=flags, tile=tile, passes=passes)
 
-    with gpu.DeviceScene(desc) as ds:
+    with gpu.DeviceScene(desc, static=(mesh is not None)) as ds:      # the bench creates its scene as static
         fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
         st_bvh = ds.render_device(rd(), fb.data_ptr())
         img_bvh = fb.clone()
@@ -551,38 +553,92 @@ def test_degenerate_scenes(gpu):
             assert np.isfinite(img).all() and rel_err(img, ref).max() < REL_TOL, make.__name__
 
 
-def test_full_size_16spp_soft_shadow_frame_properties(gpu):
-    """The 1080p 16-spp SquareLight frame of the bench's second leg at its full size (33 M
-    camera rays, ~87 M shadow rays; minutes for the CPU oracle): the BVH walk and the culled KD
-    walk must give the same image bit for bit and the same ray counts, the frame assembled from
-    interleaved row bands (the multi-GPU partition, here on one rank) must equal the frame
-    rendered at once, and the image must be finite and lit."""
+def _interleaved_rows_equal_the_frames(ds, rd_of, whole, W, H, ranks=4, group=8):
+    """Every rank's share of the frame -- the groups of `group` rows g with g % ranks == rank, one
+    tile of interleaved rows rendered in one call (dist.rank_rows) -- equals those rows of the frame
+    rendered at once; returns the rays of all shares together."""
     import torch
     from raytracer_amd import dist as rdist
-    scene, _ = scenes.mesh_scene(ggx=True, square_light=True)
+    rays = 0
+    for rank in range(ranks):
+        y0, rows, stride = rdist.rank_rows(H, ranks, rank, group)
+        part = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
+        rays += ds.render_device(rd_of(tile=(0, y0, W, rows), row_group=group, row_stride=stride), part.data_ptr()).rays
+        frame_rows = torch.cat([torch.arange(y, min(y + group, H)) for y in range(y0, H, stride)]).to("cuda")
+        assert torch.equal(part.view(torch.int32), whole[frame_rows].view(torch.int32)), rank
+    return rays
+
+
+@pytest.mark.parametrize("mesh", ["backpack", None], ids=["backpack", "procedural"])
+def test_full_size_16spp_soft_shadow_frame_properties(gpu, mesh):
+    """The 1080p 16-spp SquareLight frame of the bench's second leg at its full size (33 M
+    camera rays, ~87 M shadow rays; minutes for the CPU oracle), on the scene the bench times
+    (backpack model, 4096 x 4096 albedo map) and on the procedural mesh: the BVH walk, the culled KD
+    walk and the reference-order walk must give the same image bit for bit and the same ray counts,
+    the frame assembled from row bands and from interleaved groups of rows (the multi-GPU
+    partition, here on one rank) must equal the frame rendered at once, and the image must be
+    finite and lit."""
+    import torch
+    from raytracer_amd import dist as rdist
+    scene = scenes.frame16_scene("whitted", mesh=mesh, texture_size=4096 if mesh else 256)
     desc = scene.frame(0.0)
-    cam = scenes.orbit_camera(0.2)
     W, H = 1920, 1080
 
-    def rd(flags=0, tile=None):
-        return scenes.render_desc(W, H, integrator=abi.INTEGRATOR_WHITTED, camera=cam, n=4, light_n=2, max_depth=3,
-                                  bias=1e-2, frame=6, flags=flags, tile=tile)
+    def rd(flags=0, tile=None, row_group=0, row_stride=0):
+        return scenes.frame16_render_desc("whitted", W, H, 6, flags=flags, tile=tile, row_group=row_group, row_stride=row_stride)
 
-    with gpu.DeviceScene(desc) as ds:
+    with gpu.DeviceScene(desc, static=(mesh is not None)) as ds:
         fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
         st = ds.render_device(rd(), fb.data_ptr())
         whole = fb.clone()
         assert st.rays_primary == W * H * 16 and st.rays_shadow % 4 == 0 and st.rays_shadow > 0
-        fb.zero_()
-        st2 = ds.render_device(rd(abi.FLAG_KD_CULLED), fb.data_ptr())
-        assert (st2.rays_primary, st2.rays_shadow) == (st.rays_primary, st.rays_shadow)
-        assert torch.equal(fb, whole)
+        for flags in (abi.FLAG_KD_CULLED, abi.FLAG_REFERENCE_ORDER):
+            fb.zero_()
+            st2 = ds.render_device(rd(flags), fb.data_ptr())
+            assert (st2.rays_primary, st2.rays_shadow) == (st.rays_primary, st.rays_shadow)
+            assert torch.equal(fb.view(torch.int32), whole.view(torch.int32)), flags
         rays = [0]
 
         def render_rect(x0, y0, w, h, out):
             rays[0] += ds.render_device(rd(tile=(x0, y0, w, h)), out.data_ptr()).rays
         banded = rdist.render_frame_bands(render_rect, W, H, torch.device("cuda"), band_rows=264)
         assert torch.equal(banded, whole) and rays[0] == st.rays
+        assert _interleaved_rows_equal_the_frames(ds, rd, whole, W, H) == st.rays
+        assert torch.isfinite(whole).all() and float(whole.max()) > 0.1
+
+
+def test_full_size_16spp_path_ggx_frame_properties(gpu):
+    """The 1080p 16-spp pathTrace frame of the bench (backpack model with its 4096 x 4096 albedo map,
+    CookTorance / GGX Gp bounces to depth 8, emissive sphere; ~60 M rays) at its full size: the
+    three walks give the same image bit for bit and the same ray counts, four tiles rendered
+    separately compose to the frame, every rank's tile of interleaved 8-row groups equals its rows
+    of the frame, and the image is finite and lit."""
+    import torch
+    scene = scenes.frame16_scene("path")
+    desc = scene.frame(0.0)
+    W, H = 1920, 1080
+
+    def rd(flags=0, tile=None, row_group=0, row_stride=0):
+        return scenes.frame16_render_desc("path", W, H, 4, flags=flags, tile=tile, row_group=row_group, row_stride=row_stride)
+
+    with gpu.DeviceScene(desc, static=True) as ds:
+        fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        st = ds.render_device(rd(), fb.data_ptr())
+        whole = fb.clone()
+        assert st.rays_primary == W * H * 16 and st.rays_secondary > 0.5 * st.rays_primary and st.rays_shadow == 0
+        for flags in (abi.FLAG_KD_CULLED, abi.FLAG_REFERENCE_ORDER):
+            fb.zero_()
+            st2 = ds.render_device(rd(flags), fb.data_ptr())
+            assert (st2.rays_primary, st2.rays_secondary) == (st.rays_primary, st.rays_secondary)
+            assert torch.equal(fb.view(torch.int32), whole.view(torch.int32)), flags
+        rays = 0
+        for (x0, y0) in ((0, 0), (960, 0), (0, 536), (960, 536)):
+            w, h = 960, (536 if y0 == 0 else H - 536)
+            part = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+            rays += ds.render_device(rd(tile=(x0, y0, w, h)), part.data_ptr()).rays
+            assert torch.equal(part.view(torch.int32), whole[y0:y0 + h, x0:x0 + w].contiguous().view(torch.int32))
+        assert rays == st.rays
+        assert _interleaved_rows_equal_the_frames(ds, rd, whole, W, H, ranks=8) == st.rays
         assert torch.isfinite(whole).all() and float(whole.max()) > 0.1
 
 

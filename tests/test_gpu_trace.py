@@ -273,6 +273,41 @@ def test_kd_tree_that_leaves_shapes_out_of_leaves_they_reach(gpu):
     assert np.count_nonzero(whole["prim"] != ref["prim"]) > 20
 
 
+@pytest.mark.parametrize("static", [False, True])
+def test_single_leaf_kd_tree_that_omits_a_shape(gpu, static):
+    """A KD tree that is one leaf (fewer than seven shapes, KDTree.cpp:69) and does not list one of
+    the scene's shapes: the reference's walk never tests that shape, so rays aimed at it see what lies
+    behind.  The candidate BVH is built over all shapes and proposes it; the certificate must refuse
+    it (a tree of one leaf has no branch to locate a point with), and the render walk must report
+    what the reference-order walk reports, in traces and in pictures."""
+    import ctypes as C
+    scene, cam = scenes.whitted_scene()
+    desc = scene.frame(0.0)
+    assert desc.n_branches == 0 and desc.n_leaves == 1 and desc.kd_root < 0
+    count = np.array([desc.n_shapes - 1], dtype=np.uint32)         # the last shape (the mirror sphere) is left out
+    thin = abi.SceneDesc()
+    C.memmove(C.byref(thin), C.byref(desc), C.sizeof(thin))
+    thin.leaf_count = count.ctypes.data_as(C.POINTER(C.c_uint32))
+    rd = scenes.render_desc(160, 120, integrator=abi.INTEGRATOR_WHITTED, camera=cam, max_depth=2)
+    o, d = orc.camera_rays(rd)
+    with gpu.DeviceScene(thin, static=static) as ds:
+        ref = ds.trace_closest(o, d)
+        got = ds.trace_closest(o, d, flags=abi.FLAG_RENDER_WALK)
+        img, st = ds.render(rd)
+        rd.flags = abi.FLAG_REFERENCE_ORDER
+        img_ref, st_ref = ds.render(rd)
+    with gpu.DeviceScene(desc) as ds:
+        whole = ds.trace_closest(o, d)
+    want = orc.trace_closest(thin, o, d)
+    assert np.array_equal(ref["prim"], want["prim"]) and np.array_equal(ref["depth"], want["depth"])
+    assert np.array_equal(got["prim"], ref["prim"]), f"{np.count_nonzero(got['prim'] != ref['prim'])} ids differ"
+    assert np.array_equal(got["depth"], ref["depth"])
+    assert not np.any(ref["prim"] == desc.n_shapes - 1)
+    assert np.count_nonzero(whole["prim"] == desc.n_shapes - 1) > 100, "the omitted shape should be in view"
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (st_ref.rays_primary, st_ref.rays_secondary, st_ref.rays_shadow)
+    assert np.array_equal(img.view(np.uint32), img_ref.view(np.uint32))
+
+
 def _degenerate_scene(offset, scale=1.0):
     """Geometry chosen to sit on KD cell faces and split planes and to stress the culls'
     margins: axis-aligned quads on integer planes (their boxes are flat and coincide with

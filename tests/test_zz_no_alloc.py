@@ -91,3 +91,30 @@ def test_noalloc_refuses_what_does_not_fit(gpu):
             ds2.render_device_noalloc(rd, got.data_ptr())
             torch.cuda.synchronize()
             assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+def test_noalloc_first_call_on_a_fresh_scene_allocates_nothing(gpu):
+    """What the header promises: the entry point is usable as the FIRST render call on a handle (no
+    workspace, stream or event of an earlier rtx_render_device call to lean on) and neither it nor
+    the kernels it queues take device memory.  Free device memory is read before and after two
+    calls (hipMemGetInfo through torch); the image equals rtx_render_device's, rendered afterwards."""
+    import torch
+    scene, cam = scenes.lens_scene()
+    desc = scene.frame(0.1)
+    rd = scenes.render_desc(120, 80, integrator=abi.INTEGRATOR_PATH, camera=cam, n=2, max_depth=5, bias=1e-4, seed=9,
+                            clear=(0.2, 0.7, 0.9))
+    got = torch.zeros((80, 120, 3), dtype=torch.float32, device="cuda")
+    again = torch.zeros_like(got)
+    want = torch.zeros_like(got)
+    torch.cuda.synchronize()
+    with gpu.DeviceScene(desc) as ds:
+        free_before, _ = torch.cuda.mem_get_info()
+        ds.render_device_noalloc(rd, got.data_ptr())
+        ds.render_device_noalloc(rd, again.data_ptr())
+        torch.cuda.synchronize()
+        free_after, _ = torch.cuda.mem_get_info()
+        assert free_after == free_before, f"{free_before - free_after} bytes of device memory taken"
+        ds.render_device(rd, want.data_ptr())
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+        assert torch.equal(again.view(torch.int32), want.view(torch.int32))
+        assert float(got.max()) > 0.0

@@ -25,15 +25,18 @@ def frames_of(bench_args):
     a = bench_args.split()
     def val(flag, default):
         return int(a[a.index(flag) + 1]) if flag in a else default
-    if "main" in a[a.index("--only") + 1]:
-        return val("--steps", 60) + val("--warmup", 8)
-    return 1 + val("--frames16", 10)
+    only = a[a.index("--only") + 1]
+    if only == "main":
+        return val("--steps", 60)
+    if only == "c5":
+        return val("--c5-frames", 1)
+    return val("--frames16", 10)
 
 
 def main(tag):
     out = os.path.join(ROOT, "profiles")
     g = os.path.join(ROOT, "gpurun_out")
-    for name in ("main", "main-serial", "f16w", "f16p"):
+    for name in ("main", "main-serial", "f16w", "f16p", "f16w-serial", "f16p-serial"):
         stats = glob.glob(os.path.join(g, f"kt_{name}", "*", "*kernel_stats.csv"))
         if stats:       # gpurun merges into what earlier calls left: take the newest
             shutil.copy(max(stats, key=os.path.getmtime), os.path.join(out, f"{tag}_kernel_stats_{name}.csv"))
@@ -41,7 +44,7 @@ def main(tag):
         if os.path.exists(line):
             shutil.copy(line, os.path.join(out, f"{tag}_bench_under_rocprof_{name}.json"))
     workloads = {}
-    for wl in ("main", "f16w", "f16p"):
+    for wl in ("main", "f16w", "f16p", "c5"):
         summary = os.path.join(g, f"pmc_{wl}", "summary.json")
         args_file = os.path.join(g, f"pmc_{wl}", "bench_args.txt")
         if not (os.path.exists(summary) and os.path.exists(args_file)):
