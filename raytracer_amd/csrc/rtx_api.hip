@@ -994,6 +994,9 @@ static void hand_out_stats(rtx_scene* sc, rtx_stats* out)
     t.triangle_tests = work[3]; t.sphere_tests = work[4]; t.hits_accepted = work[5];
     t.content_tests = work[6]; t.fallback_rays = work[7];
     t.wave_steps = work[10]; t.lane_steps = work[11];
+    // RTX_PROBE=1 (with RTX_FLAG_COUNTERS): wave-level tallies of the BVH walk on stderr
+    if (std::getenv("RTX_PROBE") && (work[13] | work[14]))
+        std::fprintf(stderr, "rtx probe: wave_node_steps %llu wave_leaf_trips %llu wave_leaf_trips_packed %llu\n", work[13], work[14], work[15]);
     if (out) *out = t;
     std::memset(&t, 0, sizeof t);
 }

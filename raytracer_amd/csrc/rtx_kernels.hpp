@@ -105,6 +105,10 @@ struct Work {
     uint32_t fallback = 0;          // rays re-traced in reference order
     uint32_t leaf_count = 0;
     unsigned long long leaf_hash = 14695981039346656037ull;
+    // wave-level tallies of the BVH walk, kept by whichever lane is the first active one at the time:
+    // times the wave ran the node step, times it ran a trip of the leaf loop, and the trips it would
+    // need if a leaf phase's shape tests were dealt out over all 64 lanes
+    uint32_t wave_node = 0, wave_trip = 0, wave_trip_packed = 0;
 };
 template <>
 struct Work<false> {};
@@ -761,6 +765,8 @@ RTX_DEV void slab_f32(const SlabF32& f, float lox, float loy, float loz, float h
     tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
 }
 
+RTX_DEV bool first_active_lane();
+
 template <bool COUNT, bool ANYHIT>
 RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* stack, int32_t& best_prim,
                             double& best_depth, Work<COUNT>& w)
@@ -813,7 +819,7 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 slab_f32(f32, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, rmin, rmax);
                 left = __float_as_int(n3.x); right = __float_as_int(n3.y);
             }
-            if constexpr (COUNT) w.content += 2;
+            if constexpr (COUNT) { w.content += 2; if (first_active_lane()) w.wave_node++; }
             bool hl = lmin <= lmax && lmax >= 0.0f && !(lmin > bound32);
             bool hr = rmin <= rmax && rmax >= 0.0f && !(rmin > bound32);
             // (written without branches except for the deferred child's store)
@@ -824,6 +830,12 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 stack[sp * kTraceBlock] = left_first ? right : left;
                 ++sp;
             }
+            // (The compiler turns this `continue` into an inner loop of node steps that a lane leaves at a
+            // leaf or at a dead end, and that runs until every lane has left it; leaf code and stack pops
+            // follow for all lanes together.  Measured against it on the 16-spp frames, all slower: dead
+            // ends popping inside that inner loop, so that lanes stop for one another at leaves only
+            // (pathTrace frame 17.2 -> 20.4 ms); one node step per turn of a single loop (26.4 ms); runs
+            // of at most 2 / 4 / 8 node steps (24.4 / 22.4 / 20.6 ms).)
             if (hl || hr) {
                 node = go_left ? left : right;
                 continue;
@@ -836,7 +848,13 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
             const int32_t first_leaf = __builtin_amdgcn_readfirstlane(node);
             const bool same_leaf = __all(node == first_leaf);
             const BvhPrim* uq = s.bvh_prims + ((uint32_t)~first_leaf >> 3);
+            if constexpr (COUNT) {
+                uint32_t tests = 0;
+                for (uint32_t c = 1; c <= 8u; ++c) tests += c * (uint32_t)__popcll(__ballot(count == c));
+                if (first_active_lane()) w.wave_trip_packed += (tests + 63u) / 64u;
+            }
             for (uint32_t k = 0; k < count; ++k, ++q, ++uq) {
+                if constexpr (COUNT) { if (first_active_lane()) w.wave_trip++; }
                 // Shape::rayAABB && rayHit (KDTree.cpp:208-211) commute: rayHit first, and the
                 // shape's box is only fetched for a hit that could change the result
                 // the whole record in one go: ids and positions arrive together instead of the
@@ -901,9 +919,18 @@ RTX_DEV bool culling_is_exact(d3 o, d3 d)
     return isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
 }
 
+RTX_DEV bool first_active_lane()
+{
+    const unsigned long long m = __ballot(1);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u;
+}
+
 RTX_DEV void add_counters(Counters g, const Work<true>& w)
 {
     if (!g.c) return;
+    if (w.wave_node) atomicAdd(g.c + 13, (unsigned long long)w.wave_node);
+    if (w.wave_trip) atomicAdd(g.c + 14, (unsigned long long)w.wave_trip);
+    if (w.wave_trip_packed) atomicAdd(g.c + 15, (unsigned long long)w.wave_trip_packed);
     atomicAdd(g.c + 0, (unsigned long long)w.branch); atomicAdd(g.c + 1, (unsigned long long)w.leaf);
     atomicAdd(g.c + 2, (unsigned long long)w.aabb); atomicAdd(g.c + 3, (unsigned long long)w.tri);
     atomicAdd(g.c + 4, (unsigned long long)w.sph); atomicAdd(g.c + 5, (unsigned long long)w.accepted);
