@@ -697,6 +697,7 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
         kd_split[i].greater = branches[i].greater;
     }
     std::vector<int32_t> prim_lca(s->n_shapes, s->kd_root);
+    std::vector<uint32_t> prim_cert;        // filled for static scenes (see certify_by_stretch)
     // A shape whose leaf list provably holds EVERY leaf below that node whose cell comes within
     // hold_margin of the shape's box gets kLcaSure: a point of that box inside such a cell is then
     // in a leaf of the shape, and the device need not search the list (member_by_cell).  The
@@ -710,6 +711,7 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
     // top of a 0.12 s scene for 960 k -- more than a scene that is rebuilt for every frame earns back,
     // so it is done for scenes the caller creates as static only)
     const bool mark_sure = settled && hold_margin > 0.0 && std::isfinite(hold_margin);
+    if (mark_sure) prim_cert.assign(s->n_shapes, 0u);
     struct Sub { int32_t node; PrimBox cell; };          // a subtree and the cell its root was handed
     auto enter = [&](PrimBox& c, const Branch& b) {
         for (int k = 0; k < 3; ++k) { c.bmin[k] = std::max(c.bmin[k], b.bmin[k]); c.bmax[k] = std::min(c.bmax[k], b.bmax[k]); }
@@ -742,6 +744,69 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
             if (!look(p, it, st)) return false;
         }
         return true;
+    };
+    // The faces of KD cells that come within hold_margin of shape p's box, per axis, for the device's
+    // certificate by stretch: the faces of the covering node's cell, and below it every face a node adds
+    // to the cell it is handed -- a side of its own box that cuts into the cell, and its split plane.
+    // 0 when the box is not inside the covering node's cell, when a leaf below that node whose cell meets
+    // the box (and is thick enough to hold a point by the margin) does not list the shape, or when a
+    // count passes kCertMaxFaces.
+    // A cell thinner than this on some axis never holds a point by the device's margin (at least 1e-9 of
+    // the scene's size from every face), and neither does an inverted one: such leaves are never stood on.
+    const double thin = 2e-9 * shape_scale;
+    auto count_faces = [&](uint32_t p, const Sub& root, std::vector<Sub>& st) -> uint32_t {
+        const PrimBox& sb = boxes[p];
+        const uint32_t* ids = prim_leaf_ids.data() + prim_leaf_first[p];
+        const uint32_t* ids_end = prim_leaf_ids.data() + prim_leaf_first[p + 1];
+        uint32_t cnt[3] = {0, 0, 0};
+        auto near_box = [&](int k, double v) { return v >= sb.bmin[k] - hold_margin && v <= sb.bmax[k] + hold_margin; };
+        PrimBox top = root.cell;
+        if (root.node >= 0) enter(top, branches[root.node]);
+        for (int k = 0; k < 3; ++k) {
+            if (!(sb.bmin[k] >= top.bmin[k] && sb.bmax[k] <= top.bmax[k])) {
+                if (timings) { static std::atomic<int> shown{0}; if (shown++ < 4) std::fprintf(stderr, "cert: shape %u axis %d box [%.17g %.17g] outside covering cell [%.17g %.17g]\n", p, k, sb.bmin[k], sb.bmax[k], top.bmin[k], top.bmax[k]); }
+                return 0u;
+            }
+            if (near_box(k, top.bmin[k])) cnt[k]++;
+            if (near_box(k, top.bmax[k])) cnt[k]++;
+        }
+        st.clear();
+        st.push_back(Sub{root.node, top});
+        while (!st.empty()) {
+            const Sub it = st.back();
+            st.pop_back();
+            bool apart = false;
+            for (int k = 0; k < 3; ++k)
+                if (!(sb.bmin[k] - hold_margin <= it.cell.bmax[k] && sb.bmax[k] + hold_margin >= it.cell.bmin[k])) apart = true;
+            if (apart) continue;
+            if (it.node < 0) {
+                // a leaf that a point of the box can be inside of, by the margin, must list the shape
+                bool stands = true;
+                for (int k = 0; k < 3; ++k)
+                    if (!(it.cell.bmax[k] - it.cell.bmin[k] >= thin && sb.bmin[k] <= it.cell.bmax[k] && sb.bmax[k] >= it.cell.bmin[k])) stands = false;
+                if (stands && !std::binary_search(ids, ids_end, (uint32_t)~it.node)) {
+                    if (timings) { static std::atomic<int> shown2{0}; if (shown2++ < 4) std::fprintf(stderr, "cert: shape %u box [%.12g %.12g %.12g]-[%.12g %.12g %.12g] meets unlisted leaf %u cell [%.12g %.12g %.12g]-[%.12g %.12g %.12g]\n", p, sb.bmin[0], sb.bmin[1], sb.bmin[2], sb.bmax[0], sb.bmax[1], sb.bmax[2], (uint32_t)~it.node, it.cell.bmin[0], it.cell.bmin[1], it.cell.bmin[2], it.cell.bmax[0], it.cell.bmax[1], it.cell.bmax[2]); }
+                    return 0u;
+                }
+                continue;
+            }
+            const Branch& b = branches[it.node];
+            for (int k = 0; k < 3; ++k) {
+                if (b.bmin[k] > it.cell.bmin[k] && near_box(k, b.bmin[k])) cnt[k]++;
+                if (b.bmax[k] < it.cell.bmax[k] && near_box(k, b.bmax[k])) cnt[k]++;
+            }
+            if (near_box(b.axis, b.value)) cnt[b.axis]++;
+            if (cnt[0] > kCertMaxFaces || cnt[1] > kCertMaxFaces || cnt[2] > kCertMaxFaces) {
+                if (timings) { static std::atomic<int> shown3{0}; if (shown3++ < 4) std::fprintf(stderr, "cert: shape %u too many faces\n", p); }
+                return 0u;
+            }
+            Sub l{b.lesser, it.cell}, g{b.greater, it.cell};
+            enter(l.cell, b); enter(g.cell, b);
+            l.cell.bmax[b.axis] = std::min(l.cell.bmax[b.axis], b.value);
+            g.cell.bmin[b.axis] = std::max(g.cell.bmin[b.axis], b.value);
+            st.push_back(l); st.push_back(g);
+        }
+        return kCertValid | cnt[0] | (cnt[1] << 10) | (cnt[2] << 20);
     };
     // shapes in very many leaves (a floor: a hundred thousand) are checked afterwards, each by all threads
     constexpr uint32_t kLongList = 4096;
@@ -776,6 +841,7 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
             st.clear();
             st.push_back(Sub{node, cell});
             if (look_through(p, st)) prim_lca[p] = node | kLcaSure;
+            prim_cert[p] = count_faces(p, Sub{node, cell}, st);
         }
     }, mark_sure ? 12u : 0u);
     for (const auto& [p, root] : long_lists) {
@@ -802,6 +868,16 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
         if (ok.load()) prim_lca[p] |= kLcaSure;
     }
     lap("kd_split, prim_lca");
+    if (timings && mark_sure) {
+        size_t sure = 0, valid = 0, sum[3] = {0, 0, 0};
+        for (uint32_t p = 0; p < s->n_shapes; ++p) {
+            if (prim_lca[p] >= 0 && (prim_lca[p] & kLcaSure)) ++sure;
+            if (prim_cert[p] & kCertValid) { ++valid; for (int k = 0; k < 3; ++k) sum[k] += (prim_cert[p] >> (10 * k)) & 1023u; }
+        }
+        std::fprintf(stderr, "rtx_scene_create: %u shapes, %zu with complete leaf lists, %zu with face counts (mean %.1f / %.1f / %.1f per axis)\n",
+                     s->n_shapes, sure, valid, valid ? (double)sum[0] / valid : 0.0, valid ? (double)sum[1] / valid : 0.0,
+                     valid ? (double)sum[2] / valid : 0.0);
+    }
     bvh_done.get();
     lap("wait for the BVH");
     d.bvh_root = bvh.root;
@@ -824,6 +900,7 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
     up(prim_leaf_pos.data(), prim_leaf_pos.size(), &d.prim_leaf_pos);
     up(leaf_cell.data(), leaf_cell.size(), &d.leaf_cell);
     up(prim_lca.data(), prim_lca.size(), &d.prim_lca);
+    up(prim_cert.data(), prim_cert.size(), &d.prim_cert);
     up(kd_split.data(), kd_split.size(), &d.kd_split);
     up(leaves.data(), leaves.size(), &d.leaves);
     up(s->leaf_refs, (size_t)s->n_leaf_refs, &d.leaf_refs);

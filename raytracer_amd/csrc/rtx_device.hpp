@@ -128,6 +128,14 @@ constexpr uint32_t kKdMaxNodes = 1u << 29;
 // kHoldMargin x scene_scale of the shape's box is known to hold the shape.
 constexpr int32_t kLcaSure = 1 << 30;
 constexpr double kHoldMargin = 1e-7;
+// prim_cert[shape] (scenes created as static): kCertValid | nx | ny << 10 | nz << 20, where n_a counts the
+// faces of KD cells perpendicular to axis a -- split planes and box faces of the nodes below the
+// shape's deepest covering node, and the faces of that node's own cell -- that come within
+// kHoldMargin x scene_scale of the shape's box.  Valid only for a shape whose box lies inside that node's
+// cell and that every leaf below the node lists whose cell the box itself meets (cells too thin to
+// hold a point by the device's margin aside).  See certify_by_stretch().
+constexpr uint32_t kCertValid = 0x80000000u;
+constexpr uint32_t kCertMaxFaces = 1023u;
 // prim_lca of a shape that no leaf lists: the reference's walk never tests it, so no point of a ray
 // can certify it (the value is the code of a leaf no tree has: leaf ids stay below kKdMaxNodes)
 constexpr int32_t kLcaNone = INT32_MIN;
@@ -170,6 +178,7 @@ struct DScene {
     // whose subtree holds every leaf that references the shape
     const PrimBox* leaf_cell;
     const int32_t* prim_lca;
+    const uint32_t* prim_cert;      // per shape: cell faces near its box, per axis (0: not known)
     const KdSplit* kd_split;        // per branch: what locating a point needs, in one 16-byte load
     uint32_t n_branches, n_leaves, n_leaf_refs, n_shapes, n_prims, n_lights, n_materials, n_textures;
     double scene_scale;             // largest |coordinate| of the scene box

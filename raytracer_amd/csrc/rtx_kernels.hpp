@@ -617,7 +617,7 @@ RTX_DEV Box6 load_leaf_cell(const DScene& s, uint32_t leaf)
     return load_prim_box(s.leaf_cell, leaf, uniform, first);
 }
 
-RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 o, d3 d, double t, double margin)
+RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 o, d3 d, d3 inv, double t, double margin)
 {
     uint32_t first_shape;
     const bool shape_uniform = wave_uniform(shape, first_shape);
@@ -638,6 +638,19 @@ RTX_DEV bool member_by_cell(const DScene& s, uint32_t shape, d3 o, d3 d, double 
         return q.x >= sb.mn.x - e && q.x <= sb.mx.x + e && q.y >= sb.mn.y - e && q.y <= sb.mx.y + e &&
                q.z >= sb.mn.z - e && q.z <= sb.mx.z + e;
     };
+    // A shape whose box is flat on an axis (a floor) is hit ON that plane, and where the plane is a face of
+    // the KD cells -- the bottom of the scene box -- the hit point can never be inside a cell by the
+    // margin: the point tried first is then the one the step-back rule below would arrive at, a little
+    // earlier on the ray, which saves the first of two descents.  Any point of the ray serves; if
+    // this one fails too, the rule steps back from it.
+    if (sure) {
+        double early = 0.0;
+        if (sb.mn.x == sb.mx.x) early = __builtin_fmax(early, __builtin_fabs(inv.x));
+        if (sb.mn.y == sb.mx.y) early = __builtin_fmax(early, __builtin_fabs(inv.y));
+        if (sb.mn.z == sb.mx.z) early = __builtin_fmax(early, __builtin_fabs(inv.z));
+        const double t_early = t - (2.5 * margin) * early;
+        if (early > 0.0 && t_early > 0.0) t = t_early;
+    }
     d3 p = o + (d * t);
     uint32_t leaf = (uint32_t)~locate_leaf(s, lca, p);
     Box6 c = load_leaf_cell(s, leaf);
@@ -681,10 +694,56 @@ constexpr uint32_t kCandBehind = 0x40000000u;       // flag: the winning hit lie
 // but the shape's box test passed (it reaches in front of the origin) and the box holds the hit
 // point, so the ray is inside the box from the origin on, and every KD leaf whose cell the box
 // touches holds the shape: the point used is the middle of the ray's stretch inside the box.
+// The certificate without a search.  The candidate's own box test passed, so the ray runs inside
+// the shape's box B over a stretch [t0, t1] of its parameter, t1 >= 0.  For a shape marked kCertValid
+// the host has established that (a) B lies inside the cell of the deepest KD node covering the
+// shape's leaves, (b) every leaf below that node whose cell meets B lists the shape (which is what the
+// reference's builder does, KDTree.cpp:78-113; cells too thin to hold a point by the margin are not
+// asked), and (c) at most n_a faces of KD cells perpendicular to axis a come within kHoldMargin x
+// scene_scale of B.  A point of the stretch lies within `margin` of such a face only while the ray's
+// coordinate on the axis crosses a band of width 2 * margin, i.e. for 2 * margin / |d_a| of the
+// parameter; so all faces together spoil at most 2 * margin * sum(n_a / |d_a|) of the stretch.  If the
+// part of the stretch in front of the origin is longer than that, it holds a point x that keeps
+// `margin` from every face near B, hence from every face of the cell it is in (the others are
+// kHoldMargin x scene_scale from B, far more): x is inside its leaf's cell by the margin, so
+// traverseKDTree reaches that leaf (member_by_cell's argument), the leaf is below the covering node by
+// (a), its cell holds the point x of B and so lists the shape by (b), and the reference tests the shape
+// there.  (x is a point of the real line through the ray's origin and direction; nothing is computed
+// from it, and the rounding of the two slab parameters is far below the 64 margins of slack.)  Nothing is located:
+// two independent loads (the counts and the box) instead of a chain of a dozen dependent ones.
+// A `false` only means "not shown this way" (a flat box, a ray nearly parallel to a face, a
+// shape in too many leaves to count).
+RTX_DEV bool certify_by_stretch(const DScene& s, uint32_t shape, d3 o, d3 inv, double margin)
+{
+    uint32_t first_shape;
+    const bool shape_uniform = wave_uniform(shape, first_shape);
+    const uint32_t cert = shape_uniform ? scalar_load_4(s.prim_cert + first_shape) : s.prim_cert[shape];
+    // (an origin so far away that the margin, which grows with it, is no longer small against the
+    // distance that separates the counted faces from the others: not shown this way)
+    if (!(cert & kCertValid) || !(2.0 * margin <= kHoldMargin * s.scene_scale)) return false;
+    const Box6 b = load_prim_box(s.prim_box, shape, shape_uniform, first_shape);
+    double tmin, tmax;
+    slab_finite(b.mn, b.mx, o, inv, tmin, tmax);
+    const double stretch = tmax - __builtin_fmax(tmin, 0.0);
+    const double spoilt = (2.0 * margin) * (((double)(cert & 1023u) * __builtin_fabs(inv.x) + (double)((cert >> 10) & 1023u) * __builtin_fabs(inv.y)) +
+                                            (double)((cert >> 20) & 1023u) * __builtin_fabs(inv.z));
+    // (a factor four and a floor far above the rounding of the slab arithmetic; NaN compares false)
+    return stretch > 4.0 * spoilt + 64.0 * margin;
+}
+
 template <bool COUNT>
 RTX_DEV bool certify_winner(const DScene& s, uint32_t cand, d3 o, d3 d, d3 inv, double depth, double margin, Work<COUNT>& w)
 {
     const uint32_t shape = cand & ~(kCandTie | kCandBehind);
+#ifdef RTX_PROBE_CERT
+    if constexpr (COUNT) {
+        const bool ok = s.prim_cert && certify_by_stretch(s, shape, o, inv, margin);
+        const uint32_t n_leaves = s.prim_leaf_first[shape + 1] - s.prim_leaf_first[shape];
+        if (ok) w.wave_node++; else if (n_leaves > 4096u) {} else if (s.prim_cert[shape] & kCertValid) w.wave_trip++; else w.wave_trip_packed++;
+        if (ok) return true;
+    } else
+#endif
+    if (s.prim_cert && certify_by_stretch(s, shape, o, inv, margin)) return true;
     double t = depth;
     if (cand & kCandBehind) {
         double tmin, tmax;
@@ -692,7 +751,7 @@ RTX_DEV bool certify_winner(const DScene& s, uint32_t cand, d3 o, d3 d, d3 inv, 
         t = 0.5 * (__builtin_fmax(tmin, 0.0) + tmax);
         if (!(t > 0.0)) t = depth;          // nothing in front of the origin to stand on: the proofs below decide
     }
-    if (member_by_cell(s, shape, o, d, t, margin)) return true;
+    if (member_by_cell(s, shape, o, d, inv, t, margin)) return true;
     const d3 at = o + (d * t);
     return member_through_point<COUNT>(s, shape, at, o, d, inv, w) ||
            first_visited_position<COUNT>(s, shape, o, d, inv, w) != kNoPosition;
@@ -819,7 +878,11 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                 slab_f32(f32, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, rmin, rmax);
                 left = __float_as_int(n3.x); right = __float_as_int(n3.y);
             }
+#ifdef RTX_PROBE_CERT
+            if constexpr (COUNT) { w.content += 2; }
+#else
             if constexpr (COUNT) { w.content += 2; if (first_active_lane()) w.wave_node++; }
+#endif
             bool hl = lmin <= lmax && lmax >= 0.0f && !(lmin > bound32);
             bool hr = rmin <= rmax && rmax >= 0.0f && !(rmin > bound32);
             // (written without branches except for the deferred child's store)
@@ -848,13 +911,17 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
             const int32_t first_leaf = __builtin_amdgcn_readfirstlane(node);
             const bool same_leaf = __all(node == first_leaf);
             const BvhPrim* uq = s.bvh_prims + ((uint32_t)~first_leaf >> 3);
+#ifndef RTX_PROBE_CERT
             if constexpr (COUNT) {
                 uint32_t tests = 0;
                 for (uint32_t c = 1; c <= 8u; ++c) tests += c * (uint32_t)__popcll(__ballot(count == c));
                 if (first_active_lane()) w.wave_trip_packed += (tests + 63u) / 64u;
             }
+#endif
             for (uint32_t k = 0; k < count; ++k, ++q, ++uq) {
+#ifndef RTX_PROBE_CERT
                 if constexpr (COUNT) { if (first_active_lane()) w.wave_trip++; }
+#endif
                 // Shape::rayAABB && rayHit (KDTree.cpp:208-211) commute: rayHit first, and the
                 // shape's box is only fetched for a hit that could change the result
                 // the whole record in one go: ids and positions arrive together instead of the
