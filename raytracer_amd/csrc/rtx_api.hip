@@ -763,10 +763,7 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
         PrimBox top = root.cell;
         if (root.node >= 0) enter(top, branches[root.node]);
         for (int k = 0; k < 3; ++k) {
-            if (!(sb.bmin[k] >= top.bmin[k] && sb.bmax[k] <= top.bmax[k])) {
-                if (timings) { static std::atomic<int> shown{0}; if (shown++ < 4) std::fprintf(stderr, "cert: shape %u axis %d box [%.17g %.17g] outside covering cell [%.17g %.17g]\n", p, k, sb.bmin[k], sb.bmax[k], top.bmin[k], top.bmax[k]); }
-                return 0u;
-            }
+            if (!(sb.bmin[k] >= top.bmin[k] && sb.bmax[k] <= top.bmax[k])) return 0u;
             if (near_box(k, top.bmin[k])) cnt[k]++;
             if (near_box(k, top.bmax[k])) cnt[k]++;
         }
@@ -784,10 +781,7 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
                 bool stands = true;
                 for (int k = 0; k < 3; ++k)
                     if (!(it.cell.bmax[k] - it.cell.bmin[k] >= thin && sb.bmin[k] <= it.cell.bmax[k] && sb.bmax[k] >= it.cell.bmin[k])) stands = false;
-                if (stands && !std::binary_search(ids, ids_end, (uint32_t)~it.node)) {
-                    if (timings) { static std::atomic<int> shown2{0}; if (shown2++ < 4) std::fprintf(stderr, "cert: shape %u box [%.12g %.12g %.12g]-[%.12g %.12g %.12g] meets unlisted leaf %u cell [%.12g %.12g %.12g]-[%.12g %.12g %.12g]\n", p, sb.bmin[0], sb.bmin[1], sb.bmin[2], sb.bmax[0], sb.bmax[1], sb.bmax[2], (uint32_t)~it.node, it.cell.bmin[0], it.cell.bmin[1], it.cell.bmin[2], it.cell.bmax[0], it.cell.bmax[1], it.cell.bmax[2]); }
-                    return 0u;
-                }
+                if (stands && !std::binary_search(ids, ids_end, (uint32_t)~it.node)) return 0u;
                 continue;
             }
             const Branch& b = branches[it.node];
@@ -796,10 +790,7 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
                 if (b.bmax[k] < it.cell.bmax[k] && near_box(k, b.bmax[k])) cnt[k]++;
             }
             if (near_box(b.axis, b.value)) cnt[b.axis]++;
-            if (cnt[0] > kCertMaxFaces || cnt[1] > kCertMaxFaces || cnt[2] > kCertMaxFaces) {
-                if (timings) { static std::atomic<int> shown3{0}; if (shown3++ < 4) std::fprintf(stderr, "cert: shape %u too many faces\n", p); }
-                return 0u;
-            }
+            if (cnt[0] > kCertMaxFaces || cnt[1] > kCertMaxFaces || cnt[2] > kCertMaxFaces) return 0u;
             Sub l{b.lesser, it.cell}, g{b.greater, it.cell};
             enter(l.cell, b); enter(g.cell, b);
             l.cell.bmax[b.axis] = std::min(l.cell.bmax[b.axis], b.value);

@@ -735,14 +735,6 @@ template <bool COUNT>
 RTX_DEV bool certify_winner(const DScene& s, uint32_t cand, d3 o, d3 d, d3 inv, double depth, double margin, Work<COUNT>& w)
 {
     const uint32_t shape = cand & ~(kCandTie | kCandBehind);
-#ifdef RTX_PROBE_CERT
-    if constexpr (COUNT) {
-        const bool ok = s.prim_cert && certify_by_stretch(s, shape, o, inv, margin);
-        const uint32_t n_leaves = s.prim_leaf_first[shape + 1] - s.prim_leaf_first[shape];
-        if (ok) w.wave_node++; else if (n_leaves > 4096u) {} else if (s.prim_cert[shape] & kCertValid) w.wave_trip++; else w.wave_trip_packed++;
-        if (ok) return true;
-    } else
-#endif
     if (s.prim_cert && certify_by_stretch(s, shape, o, inv, margin)) return true;
     double t = depth;
     if (cand & kCandBehind) {
@@ -871,24 +863,22 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
                          __uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11]), rmin, rmax);
                 left = (int32_t)v[12]; right = (int32_t)v[13];
             } else {
-                // one node = four 16-byte loads
-                const float4* n = reinterpret_cast<const float4*>(s.bvh_nodes + node);
+                // one node = four 16-byte loads (at a 32-bit byte offset from the array's base, which stays in
+                // scalar registers: the node array is below 2^30 bytes, kBvhMaxShapes)
+                const float4* n = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.bvh_nodes) + ((uint32_t)node << 6));
                 const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
                 slab_f32(f32, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lmin, lmax);
                 slab_f32(f32, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, rmin, rmax);
                 left = __float_as_int(n3.x); right = __float_as_int(n3.y);
             }
-#ifdef RTX_PROBE_CERT
-            if constexpr (COUNT) { w.content += 2; }
-#else
             if constexpr (COUNT) { w.content += 2; if (first_active_lane()) w.wave_node++; }
-#endif
             bool hl = lmin <= lmax && lmax >= 0.0f && !(lmin > bound32);
             bool hr = rmin <= rmax && rmax >= 0.0f && !(rmin > bound32);
             // (written without branches except for the deferred child's store)
             const bool both = hl && hr;
             const bool left_first = lmin <= rmin;
-            const bool go_left = both ? left_first : hl;
+            // (lane masks combined with scalar instructions, no selects)
+            const bool go_left = (both && left_first) || (!both && hl);
             if (both) {
                 stack[sp * kTraceBlock] = left_first ? right : left;
                 ++sp;
@@ -905,23 +895,20 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
             }
         } else {
             const uint32_t code = (uint32_t)~node;
-            const BvhPrim* q = s.bvh_prims + (code >> 3);
+            // (records at 32-bit byte offsets from the array's base: at most 2^24 of 80 bytes each)
+            const BvhPrim* q = reinterpret_cast<const BvhPrim*>(reinterpret_cast<const char*>(s.bvh_prims) + (code >> 3) * (uint32_t)sizeof(BvhPrim));
             const uint32_t count = (code & 7u) + 1u;
             // all lanes that stand at a leaf stand at this one: its records come through the scalar cache
             const int32_t first_leaf = __builtin_amdgcn_readfirstlane(node);
             const bool same_leaf = __all(node == first_leaf);
             const BvhPrim* uq = s.bvh_prims + ((uint32_t)~first_leaf >> 3);
-#ifndef RTX_PROBE_CERT
             if constexpr (COUNT) {
                 uint32_t tests = 0;
                 for (uint32_t c = 1; c <= 8u; ++c) tests += c * (uint32_t)__popcll(__ballot(count == c));
                 if (first_active_lane()) w.wave_trip_packed += (tests + 63u) / 64u;
             }
-#endif
             for (uint32_t k = 0; k < count; ++k, ++q, ++uq) {
-#ifndef RTX_PROBE_CERT
                 if constexpr (COUNT) { if (first_active_lane()) w.wave_trip++; }
-#endif
                 // Shape::rayAABB && rayHit (KDTree.cpp:208-211) commute: rayHit first, and the
                 // shape's box is only fetched for a hit that could change the result
                 // the whole record in one go: ids and positions arrive together instead of the
