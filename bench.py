@@ -208,6 +208,10 @@ def main():
                          "to the backpack model, Models/backpack/1001_albedo.jpg; 256: the small checker of earlier rounds)")
     ap.add_argument("--frames16-in-flight", type=int, default=3,
                     help="frames of the 16-spp sequence kept in flight for the `pipelined` figure (0: leave it out)")
+    ap.add_argument("--checksums", action="store_true",
+                    help="tests: the byte sum of every presented frame the pipelined legs deliver on rank 0 (slows them down)")
+    ap.add_argument("--sequence-leg", action="store_true",
+                    help="run the whole-frames partition of the 16-spp sequence on one rank too (with N > 1 it always runs)")
     ap.add_argument("--only", choices=["all", "main", "f16w", "f16p", "c5"], default="all",
                     help="run one workload only (profiling runs)")
     ap.add_argument("--pmc-run", action="store_true",
@@ -616,7 +620,7 @@ def frame_16spp(ctx, kind):
     pipelined = sequence = None
     if args.frames16_in_flight > 0 and not args.pmc_run:
         pipelined = pipelined_frames(ctx, kind, ds, rd_for, frames, args.frames16_in_flight, "rows")
-        if world > 1:
+        if world > 1 or args.sequence_leg:
             sequence = pipelined_frames(ctx, kind, ds, rd_for, frames, args.frames16_in_flight, "frames")
     out = None
     if rank == 0:
@@ -702,10 +706,18 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight, partition):
     pending = [None] * F
     tonemap = abi.TONEMAP_CBRT if kind == "path" else abi.TONEMAP_NONE
 
+    checksums = {}                                       # frame -> sum of its presented bytes, as rank 0 holds them
+    frame_of = [None] * F
+
     def place(k):
         # frame row (j * world + r) * 8 + i  <-  rank r, packed row j * 8 + i
         if by_rows:
             frame_buf[k].view(per_rank, world, 8, W, 3).copy_(gathered[k].view(world, per_rank, 8, W, 3).transpose(0, 1))
+            if args.checksums:
+                checksums[frame_of[k]] = int(frame_buf[k][:H].sum(dtype=torch.int64).item())
+        elif args.checksums:
+            for r in range(world):
+                checksums[frame_of[k] * world + r] = int(gathered[k][r].sum(dtype=torch.int64).item())
 
     def step(j):
         # the j-th step of this rank: frame j split by rows, or this rank's own frame j * world + rank
@@ -725,7 +737,11 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight, partition):
                                           flip=not by_rows)
             if world > 1:
                 src = shown[k] if backend == "nccl" else shown[k].cpu()
+                frame_of[k] = j
                 pending[k] = dist.gather(src, list(gathered[k].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
+            elif args.checksums:
+                # (one rank: the presented frame is the frame; summed at once, which waits for it)
+                checksums[f] = int(shown[k][:rows].sum(dtype=torch.int64).item())
 
     def drain():
         for k in range(F):
@@ -765,7 +781,7 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight, partition):
     if rank != 0:
         return None
     total_frames = frames if by_rows else frames * world
-    return {"partition": partition, "frames_in_flight": F, "frames": total_frames,
+    return {"partition": partition, **({"checksums": {str(k): v for k, v in sorted(checksums.items())}} if args.checksums else {}), "frames_in_flight": F, "frames": total_frames,
             "ms_per_frame": round(dt / total_frames * 1e3, 3),
             "Mrays_per_s": round(tt[1].item() / dt / 1e6, 1), "n_gpus": world,
             "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (HIP default)"),

@@ -23,15 +23,28 @@ def _free_port():
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_print_one_line_with_both_scalings(gpu):
     env = dict(os.environ, BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    common = ["--steps", "4", "--warmup", "2", "--repeats", "0", "--frames16", "4", "--width", "320", "--height", "184", "--mesh", "teapot",
+              "--texture-size", "256", "--no-cpu-baseline", "--no-serial-leg", "--no-configs", "--checksums"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--repeats", "0", "--frames16", "2", "--width", "320", "--height", "184", "--mesh", "teapot", "--no-cpu-baseline",
-           "--no-serial-leg"]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
+    # the same frames on one rank: both partitions must deliver the same presented frames, byte for byte
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--sequence-leg", "--only", "f16w"] + common,
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert one.returncode == 0, one.stderr[-2000:]
+    alone = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])["frame_16spp"]["whitted_area_light"]
+    two = out["frame_16spp"]["whitted_area_light"]
+    for leg in ("pipelined", "sequence"):
+        a, b = alone[leg]["checksums"], two[leg]["checksums"]
+        shared = sorted(set(a) & set(b))
+        # (the orbit camera is inside the teapot, which is much larger than the backpack: most frames are dark)
+        assert len(shared) >= 2 and all(a[k] == b[k] for k in shared) and any(a[k] > 0 for k in shared), (leg, a, b)
+    assert two["sequence"]["partition"] == "frames" and two["sequence"]["frames"] == 8 and two["sequence"]["n_gpus"] == 2
+    assert out["strong_scaling"]["whitted_area_light"]["sequence_ms_per_frame"] == two["sequence"]["ms_per_frame"]
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["steps"] == 4 and out["warmup"] == 2
     for kind in ("whitted_area_light", "path_ggx"):
