@@ -568,9 +568,26 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
                            (s->lights[0].kind == RTX_LIGHT_POINT || s->lights[0].kind == RTX_LIGHT_DIRECTIONAL);
     lap("copy branches, boxes");
     BvhBuild bvh;
+    int32_t bvh_behind_root = kBvhEmpty;
     std::vector<BvhPrim> bvh_prims;
     std::future<void> bvh_done = std::async(std::launch::async, [&]() {
-        build_bvh(boxes, s->n_shapes, bvh);
+        // (RTX_BVH_SPLIT_AREA: the box area, in medians of the scene, above which a triangle enters the
+        // BVH in pieces; 0 = every shape whole)
+        double split_factor = kBvhSplitArea;
+        if (const char* env = std::getenv("RTX_BVH_SPLIT_AREA")) split_factor = std::atof(env);
+        std::vector<PrimBox> ref_boxes, part_boxes;
+        std::vector<uint32_t> ref_shape, part_shape;
+        if (split_factor > 0.0) split_large_triangles(boxes, s->n_shapes, info.data(), s->tri_position, split_factor, ref_boxes, ref_shape, part_boxes, part_shape);
+        if (!part_boxes.empty() && ref_boxes.size() <= kBvhMaxShapes) {
+            build_bvh(ref_boxes, (uint32_t)ref_boxes.size(), bvh, &ref_shape);
+            BvhBuild behind;
+            build_bvh(part_boxes, (uint32_t)part_boxes.size(), behind, &part_shape);
+            bvh_behind_root = append_bvh(bvh, behind);
+            if (timings) std::fprintf(stderr, "rtx_scene_create: %u shapes as %zu BVH references, %zu of them pieces of split triangles\n",
+                                      s->n_shapes, ref_boxes.size(), part_boxes.size());
+        } else {
+            build_bvh(boxes, s->n_shapes, bvh);
+        }
         bvh_prims.resize(bvh.prims.size());
         for (size_t i = 0; i < bvh.prims.size(); ++i) {
             BvhPrim& q = bvh_prims[i];
@@ -872,6 +889,7 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
     bvh_done.get();
     lap("wait for the BVH");
     d.bvh_root = bvh.root;
+    d.bvh_behind_root = bvh_behind_root;
     sc->bvh_depth = (uint32_t)bvh.depth;
     d.scene_scale = shape_scale;
 

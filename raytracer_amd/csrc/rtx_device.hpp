@@ -152,6 +152,17 @@ struct BvhNode {                // 64 bytes
     int32_t pad[2];
 };
 constexpr int32_t kBvhEmpty = INT32_MIN;
+// Large triangles enter the BVH in pieces (rtx_bvh.hpp: split_large_triangles): several boxes, each
+// around a part of the triangle, in place of the one box around all of it.  A hit in front of the
+// ray's origin lies in a piece's box that the ray enters, so the walk proposes it as before.  But
+// Triangle::rayHit also reports a front-facing triangle BEHIND the origin (no test of the
+// parameter's sign), and the reference accepts it whenever the ray passes the triangle's own box,
+// i.e. whenever the origin lies inside that box: with one box per triangle the walk arrives at such a
+// triangle anyway (its box surrounds the origin), with pieces it need not.  The pieces of the split
+// triangles therefore also form a second, small BVH (bvh_behind_root, in the same arrays) that is
+// walked with the REVERSED ray after the first: a hit behind the origin lies in a piece's box that
+// the reversed ray enters, within the same distance bound.  Shapes are tested with the ray itself in
+// both walks, so a triangle met twice answers the same twice.
 constexpr uint32_t kBvhMaxShapes = 1u << 24;     // 4 per leaf under the BVH depth cap of 22
 
 // The shapes of the BVH leaves, in leaf order, with what the traversal needs inline so a
@@ -165,6 +176,7 @@ struct BvhPrim {                // 80 bytes
 struct DScene {
     int32_t root;
     int32_t bvh_root;
+    int32_t bvh_behind_root;        // the BVH over the pieces of the triangles that were split (kBvhEmpty: none were)
     const BvhNode* bvh_nodes;
     const BvhPrim* bvh_prims;
     // inverse leaf index: the KD leaves that reference shape p are

@@ -806,6 +806,15 @@ RTX_DEV SlabF32 make_slab_f32(const DScene& s, d3 o, d3 inv)
     slab_f32_axis(o.z, inv.z, scale, f.iz, f.az, f.bz);
     return f;
 }
+// The same for the ray from the same origin in the opposite direction: 1/d and o/d change sign,
+// delta does not, and the plane met first becomes the one met last, so every constant is negated
+// (each parameter is minus the forward one, rounded the same, and entry and exit swap).
+RTX_DEV void reverse_slab_f32(SlabF32& f)
+{
+    f.ix = -f.ix; f.iy = -f.iy; f.iz = -f.iz;
+    f.ax = -f.ax; f.ay = -f.ay; f.az = -f.az;
+    f.bx = -f.bx; f.by = -f.by; f.bz = -f.bz;
+}
 // entry and exit parameter (widened) of the box [lo, hi]
 RTX_DEV void slab_f32(const SlabF32& f, float lox, float loy, float loz, float hix, float hiy, float hiz, float& tn, float& tf)
 {
@@ -840,12 +849,17 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
     // vectors, so the ray parameter is the distance from the origin up to rounding, every hit
     // point the reference computes lies on the ray and in its shape's box up to rounding, and
     // the margin (1e-7 relative + 1e-9 of the scene) is far above those errors.
-    const SlabF32 f32 = make_slab_f32(s, o, inv);
+    SlabF32 f32 = make_slab_f32(s, o, inv);
     // the bound as the single-precision test uses it: not below the FP64 one
     float bound32 = __builtin_huge_valf();
     if constexpr (ANYHIT) bound32 = float_not_below(limit * (1.0 + 1e-7) + margin());
     int sp = 0;
     int32_t node = s.bvh_root;
+    // the second walk (pieces of split triangles, ray reversed: see kBvhEmpty's note) waits at the
+    // bottom of the stack, as an entry that is neither a node nor a leaf code, so that the loop keeps
+    // its one way out (sp == 0).  (Written as a second exit test on a per-lane flag, the loop was
+    // compiled with lanes that had finished early restarted at the entry's value: a memory fault.)
+    if (s.bvh_behind_root != kBvhEmpty) { stack[0] = kBvhEmpty; sp = 1; }
     bool done = false;
     while (!done) {
         if (node >= 0) {
@@ -961,6 +975,12 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
         if (done || sp == 0) break;
         --sp;
         node = stack[sp * kTraceBlock];
+        if (node == kBvhEmpty) {
+            // the first walk is over: now the tree of the pieces, boxes tested against the reversed ray
+            // (shapes against the ray itself)
+            reverse_slab_f32(f32);
+            node = s.bvh_behind_root;
+        }
     }
     if (best_prim < 0) return true;                 // no geometric candidate at all: the reference finds none either
     if (tie) return false;
@@ -1299,6 +1319,7 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
                     bound32 = ANYHIT ? float_not_below(lim * (1.0 + 1e-7) + abs_margin) : __builtin_huge_valf();
                     best_prim = -1; best_depth = kInf; best_shape = 0; tie = false;
                     sp = 0; node = s.bvh_root; leaf_k = 0;
+                    if (s.bvh_behind_root != kBvhEmpty) { stack[0] = kBvhEmpty; sp = 1; }      // (as in trace_lane_bvh)
                     pending = true;
                     have = exact && s.bvh_root != kBvhEmpty;
                 }
@@ -1376,7 +1397,11 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
             }
             if (pop) {
                 if (sp == 0) have = false;
-                else { --sp; node = stack[sp * kTraceBlock]; }
+                else {
+                    --sp;
+                    node = stack[sp * kTraceBlock];
+                    if (node == kBvhEmpty) { reverse_slab_f32(f32); node = s.bvh_behind_root; }
+                }
             }
         }
     }
