@@ -902,6 +902,12 @@ static int scene_create(const rtx_scene_desc* s, rtx_scene** out, bool settled)
     up(branch_cbox.data(), branch_cbox.size(), &d.branch_cbox);
     up(leaf_cbox.data(), leaf_cbox.size(), &d.leaf_cbox);
     up(bvh.nodes.data(), bvh.nodes.size(), &d.bvh_nodes);
+    // (RTX_BVH_NODES=32 keeps the walk on the single-precision nodes)
+    std::vector<BvhNode16> nodes16;
+    const char* nodes_env = std::getenv("RTX_BVH_NODES");
+    const bool half_nodes = !(nodes_env && std::atoi(nodes_env) == 32) && nodes_to_half(bvh.nodes, nodes16);
+    if (timings) std::fprintf(stderr, "rtx_scene_create: %zu BVH nodes, walked in %s precision\n", bvh.nodes.size(), half_nodes ? "half" : "single");
+    if (half_nodes) up(nodes16.data(), nodes16.size(), &d.bvh_nodes16);
     up(srgb_thresholds(), 256, &sc->srgb_thresholds);
     up(bvh_prims.data(), bvh_prims.size(), &d.bvh_prims);
     up(prim_leaf_first.data(), prim_leaf_first.size(), &d.prim_leaf_first);

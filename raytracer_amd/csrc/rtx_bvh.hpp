@@ -331,6 +331,59 @@ inline void build_bvh(const std::vector<PrimBox>& boxes, uint32_t n_refs, BvhBui
     out.root = b.build(out, 0, n_refs, 0);
 }
 
+// half-precision bit patterns that do not lie inside (x, x): rounding outwards (|x| <= 65504)
+inline uint16_t half_bits(float x, bool up)
+{
+    _Float16 h = (_Float16)x;                       // nearest
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    const float back = (float)h;
+    if (up ? back < x : back > x) {
+        // one step towards +inf (up) or -inf: on the bit pattern, away from zero for the matching sign
+        const bool negative = (b & 0x8000u) != 0;
+        if ((b & 0x7fffu) == 0) b = up ? 0x0001u : 0x8001u;             // from +-0 to the smallest subnormal
+        else if (negative == !up) b = (uint16_t)(b + 1);                  // magnitude grows
+        else b = (uint16_t)(b - 1);                                       // magnitude shrinks
+    }
+    return b;
+}
+inline float half_value(uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return (float)h; }
+// The nodes with their planes in half precision, rounded outwards -- if that serves the scene: half
+// precision has 11 bits, so boxes far from the origin of coordinates grow by 2^-10 of their distance
+// from it, which is nothing to a model that sits around the origin and ruinous to small shapes at
+// coordinate 1000.  The measure is the summed surface area of all child boxes (what the expected
+// number of node visits goes with); false, and `out` empty, when it grows by more than `tolerance` or
+// a coordinate is beyond half precision's range.
+inline bool nodes_to_half(const std::vector<BvhNode>& in, std::vector<BvhNode16>& out, double tolerance = 0.03)
+{
+    out.clear();
+    if (in.empty()) return false;
+    out.resize(in.size());
+    auto area = [](const float* mn, const float* mx) {
+        const double x = (double)mx[0] - mn[0], y = (double)mx[1] - mn[1], z = (double)mx[2] - mn[2];
+        return x * y + y * z + z * x;
+    };
+    double exact = 0.0, loose = 0.0;
+    for (size_t i = 0; i < in.size(); ++i) {
+        const BvhNode& n = in[i];
+        BvhNode16& o = out[i];
+        float mn[2][3], mx[2][3];
+        for (int k = 0; k < 3; ++k) {
+            const float v[4] = {n.lmin[k], n.lmax[k], n.rmin[k], n.rmax[k]};
+            for (float x : v) if (!(std::fabs(x) <= 65000.0f)) { out.clear(); return false; }
+            o.planes[k] = half_bits(n.lmin[k], false); o.planes[3 + k] = half_bits(n.lmax[k], true);
+            o.planes[6 + k] = half_bits(n.rmin[k], false); o.planes[9 + k] = half_bits(n.rmax[k], true);
+            mn[0][k] = half_value(o.planes[k]); mx[0][k] = half_value(o.planes[3 + k]);
+            mn[1][k] = half_value(o.planes[6 + k]); mx[1][k] = half_value(o.planes[9 + k]);
+        }
+        o.left = n.left; o.right = n.right;
+        exact += area(n.lmin, n.lmax) + area(n.rmin, n.rmax);
+        loose += area(mn[0], mx[0]) + area(mn[1], mx[1]);
+    }
+    if (!(loose <= exact * (1.0 + tolerance))) { out.clear(); return false; }
+    return true;
+}
+
 // appends the tree `sub` to `out` (nodes and leaf runs renumbered) and returns its root there
 inline int32_t append_bvh(BvhBuild& out, const BvhBuild& sub)
 {

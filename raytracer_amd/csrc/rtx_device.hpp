@@ -151,6 +151,12 @@ struct BvhNode {                // 64 bytes
     int32_t left, right;
     int32_t pad[2];
 };
+// The same node with its twelve planes in half precision, rounded outwards: 32 bytes, two 16-byte
+// loads per lane.  planes[0..5] = left child (min x y z, max x y z), planes[6..11] = right child.
+struct BvhNode16 {
+    uint16_t planes[12];
+    int32_t left, right;
+};
 constexpr int32_t kBvhEmpty = INT32_MIN;
 // Large triangles enter the BVH in pieces (rtx_bvh.hpp: split_large_triangles): several boxes, each
 // around a part of the triangle, in place of the one box around all of it.  A hit in front of the
@@ -178,6 +184,7 @@ struct DScene {
     int32_t bvh_root;
     int32_t bvh_behind_root;        // the BVH over the pieces of the triangles that were split (kBvhEmpty: none were)
     const BvhNode* bvh_nodes;
+    const BvhNode16* bvh_nodes16;   // null: the scene's coordinates do not fit half precision well enough
     const BvhPrim* bvh_prims;
     // inverse leaf index: the KD leaves that reference shape p are
     // prim_leaf_ids[prim_leaf_first[p] .. prim_leaf_first[p+1]) in increasing order, and

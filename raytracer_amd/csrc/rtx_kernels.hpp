@@ -825,9 +825,26 @@ RTX_DEV void slab_f32(const SlabF32& f, float lox, float loy, float loz, float h
     tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
 }
 
+// The same test on a child box kept in half precision (BvhNode16): w0 = (min.x, min.y), w1 = (min.z,
+// max.x), w2 = (max.y, max.z) as pairs of halves.  A half converts to single precision exactly and the
+// multiply-add takes it as it is (v_fma_mix_f32), so the arithmetic and its error bound are those above;
+// a plane rounded outwards to half precision lies at most 2^-10 beyond the scene's box, which the factor
+// 1.001 on scene_scale in make_slab_f32 covers.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+RTX_DEV void slab_f16(const SlabF32& f, uint32_t w0, uint32_t w1, uint32_t w2, float& tn, float& tf)
+{
+    const half2_t a = __builtin_bit_cast(half2_t, w0), b = __builtin_bit_cast(half2_t, w1), c = __builtin_bit_cast(half2_t, w2);
+    const float x0 = fmaf((float)a.x, f.ix, f.ax), x1 = fmaf((float)b.y, f.ix, f.bx);
+    const float y0 = fmaf((float)a.y, f.iy, f.ay), y1 = fmaf((float)c.x, f.iy, f.by);
+    const float z0 = fmaf((float)b.x, f.iz, f.az), z1 = fmaf((float)c.y, f.iz, f.bz);
+    tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+}
+
 RTX_DEV bool first_active_lane();
 
-template <bool COUNT, bool ANYHIT>
+// N16: the nodes are read from DScene::bvh_nodes16 (the caller has seen that the scene has them)
+template <bool COUNT, bool ANYHIT, bool N16>
 RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* stack, int32_t& best_prim,
                             double& best_depth, Work<COUNT>& w)
 {
@@ -866,7 +883,22 @@ RTX_DEV bool trace_lane_bvh(const DScene& s, d3 o, d3 d, double limit, int32_t* 
             float lmin, lmax, rmin, rmax;
             int32_t left, right;
             const int32_t first_node = __builtin_amdgcn_readfirstlane(node);
-            if (__all(node == first_node)) {
+            const bool same_node = __all(node == first_node);
+            if constexpr (N16) {
+                // a 32-byte node: one scalar load, or two 16-byte loads per lane instead of four
+                if (same_node) {
+                    const u32x8 v = scalar_load_32(s.bvh_nodes16 + first_node);
+                    slab_f16(f32, v[0], v[1], v[2], lmin, lmax);
+                    slab_f16(f32, v[3], v[4], v[5], rmin, rmax);
+                    left = (int32_t)v[6]; right = (int32_t)v[7];
+                } else {
+                    const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(s.bvh_nodes16) + ((uint32_t)node << 5));
+                    const uint4 n0 = n[0], n1 = n[1];
+                    slab_f16(f32, n0.x, n0.y, n0.z, lmin, lmax);
+                    slab_f16(f32, n0.w, n1.x, n1.y, rmin, rmax);
+                    left = (int32_t)n1.z; right = (int32_t)n1.w;
+                }
+            } else if (same_node) {
                 // every lane of the wave that stands at a node stands at this one: the node comes
                 // through the scalar cache in one load, not through the vector memory pipeline, and
                 // the slab arithmetic takes its boxes straight from the scalar registers
@@ -1144,7 +1176,8 @@ k_trace_api(DScene s, const double* __restrict__ origin, const double* __restric
     bool settled = false;
     if (MODE != 0 && linear == 0 && culling_is_exact(r.o, r.d)) {
         if (MODE == 1) { trace_lane_culled<true, false>(s, r.o, r.d, kInf, stack + threadIdx.x, bp, bd, w); settled = true; }
-        else settled = trace_lane_bvh<true, false>(s, r.o, r.d, kInf, stack + threadIdx.x, bp, bd, w);
+        else settled = s.bvh_nodes16 ? trace_lane_bvh<true, false, true>(s, r.o, r.d, kInf, stack + threadIdx.x, bp, bd, w)
+                                     : trace_lane_bvh<true, false, false>(s, r.o, r.d, kInf, stack + threadIdx.x, bp, bd, w);
     }
     if (!settled)
         trace_lane<true>(s, r.o, r.d, linear != 0, stack + threadIdx.x, bp, bd, w,
@@ -1231,8 +1264,13 @@ k_trace_pool(DScene s, const double* __restrict__ ox, const double* __restrict__
     if (MODE != 0 && linear == 0 && culling_is_exact(o, d)) {
         if (MODE == 1) { trace_lane_culled<COUNT, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w); settled = true; }
         else if (MODE == 2) { trace_lane_culled<COUNT, true>(s, o, d, lim, stack + threadIdx.x, bp, bd, w); settled = true; }
-        else if (MODE == 3) settled = trace_lane_bvh<COUNT, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w);
-        else settled = trace_lane_bvh<COUNT, true>(s, o, d, lim, stack + threadIdx.x, bp, bd, w);
+        else if (MODE == 3) {
+            settled = s.bvh_nodes16 ? trace_lane_bvh<COUNT, false, true>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w)
+                                    : trace_lane_bvh<COUNT, false, false>(s, o, d, kInf, stack + threadIdx.x, bp, bd, w);
+        } else {
+            settled = s.bvh_nodes16 ? trace_lane_bvh<COUNT, true, true>(s, o, d, lim, stack + threadIdx.x, bp, bd, w)
+                                    : trace_lane_bvh<COUNT, true, false>(s, o, d, lim, stack + threadIdx.x, bp, bd, w);
+        }
     }
     if (!settled) {
         if constexpr (COUNT) w.fallback++;
@@ -1332,16 +1370,26 @@ k_trace_refill(DScene s, const double* __restrict__ ox, const double* __restrict
         if (have) {
             bool pop = true;
             if (node >= 0) {
-                // one node = four 16-byte loads
-                const float4* nd = reinterpret_cast<const float4*>(s.bvh_nodes + node);
-                const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
                 float lmin, lmax, rmin, rmax;
-                slab_f32(f32, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lmin, lmax);
-                slab_f32(f32, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, rmin, rmax);
+                int32_t left, right;
+                if (s.bvh_nodes16) {
+                    // (the node format trace_lane_bvh uses for this scene: the same boxes, the same walk)
+                    const uint4* nd = reinterpret_cast<const uint4*>(s.bvh_nodes16 + node);
+                    const uint4 n0 = nd[0], n1 = nd[1];
+                    slab_f16(f32, n0.x, n0.y, n0.z, lmin, lmax);
+                    slab_f16(f32, n0.w, n1.x, n1.y, rmin, rmax);
+                    left = (int32_t)n1.z; right = (int32_t)n1.w;
+                } else {
+                    // one node = four 16-byte loads
+                    const float4* nd = reinterpret_cast<const float4*>(s.bvh_nodes + node);
+                    const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                    slab_f32(f32, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, lmin, lmax);
+                    slab_f32(f32, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, rmin, rmax);
+                    left = __float_as_int(n3.x); right = __float_as_int(n3.y);
+                }
                 if constexpr (COUNT) w.content += 2;
                 const bool hl = lmin <= lmax && lmax >= 0.0f && !(lmin > bound32);
                 const bool hr = rmin <= rmax && rmax >= 0.0f && !(rmin > bound32);
-                const int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
                 if (hl && hr) {
                     const bool left_first = lmin <= rmin;
                     stack[sp * kTraceBlock] = left_first ? right : left;

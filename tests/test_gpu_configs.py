@@ -142,9 +142,10 @@ def test_reference_fbx_model_on_the_hot_path(gpu, mesh, integrator):
         assert stats.rays_shadow > 0 and stats.fallback_rays <= stats.rays // 100
 
 
-@pytest.mark.parametrize("kind,split", [("whitted", None), ("path", None), ("whitted", "16"), ("path", "16")],
-                         ids=["whitted", "path", "whitted-split", "path-split"])
-def test_bench_16spp_scenes_reduced_against_the_oracle(gpu, kind, split, monkeypatch):
+@pytest.mark.parametrize("kind,env", [("whitted", {}), ("path", {}), ("whitted", {"RTX_BVH_SPLIT_AREA": "16"}),
+                                      ("path", {"RTX_BVH_SPLIT_AREA": "16"}), ("path", {"RTX_BVH_NODES": "32"})],
+                         ids=["whitted", "path", "whitted-split", "path-split", "path-nodes32"])
+def test_bench_16spp_scenes_reduced_against_the_oracle(gpu, kind, env, monkeypatch):
     """The two scenes bench.py times as BASELINE configs[3] -- the backpack model with GGX material
     parameters and a 4096 x 4096 albedo map addressed by the model's uvs, checker floor, and either
     the 1x1 SquareLight sampled 2x2 per hit under rayTrace (Raytracer-Noah-Desktop.cpp:479-498,754)
@@ -153,9 +154,11 @@ def test_bench_16spp_scenes_reduced_against_the_oracle(gpu, kind, split, monkeyp
     equal, RGB within 1e-4 relative / 60 dB.  The `split` cases build the candidate BVH with the
     model's large triangles in pieces (RTX_BVH_SPLIT_AREA, read when the scene is created): hits BEHIND
     a ray's origin, which Triangle::rayHit reports and the reference accepts, then come from the
-    second walk with the ray reversed -- without it these scenes lose 4 % of their bounce rays."""
-    if split:
-        monkeypatch.setenv("RTX_BVH_SPLIT_AREA", split)
+    second walk with the ray reversed -- without it these scenes lose 4 % of their bounce rays.
+    `nodes32` keeps the walk on the single-precision BVH nodes (this model's tree is otherwise walked
+    on half-precision ones)."""
+    for name, value in env.items():
+        monkeypatch.setenv(name, value)
     scene = scenes.frame16_scene(kind)
     desc = scene.frame(0.0)
     assert desc.n_triangles == 67908 + 2 and desc.n_texel_bytes == 4096 * 4096 * 3

@@ -96,3 +96,33 @@ def test_f32_bound_is_not_below_the_f64_one():
     rng = np.random.default_rng(5)
     for x in np.concatenate([rng.uniform(-1e6, 1e6, 1000), 10.0 ** rng.uniform(-30, 30, 1000), [0.0, np.inf]]):
         assert float(not_below(x)) >= x
+
+
+def half_outwards(v, up):
+    """The half-precision value not inside (v, v): what rtx_bvh.hpp: half_bits stores for a plane."""
+    h = np.float16(v)
+    if (up and float(h) < float(v)) or (not up and float(h) > float(v)):
+        h = np.nextafter(h, np.float16(np.inf if up else -np.inf))
+    return h
+
+
+def test_half_precision_planes_never_refuse_what_the_f64_test_enters():
+    """BvhNode16: the same arithmetic on planes rounded outwards once more, to half precision (a
+    half converts to single precision exactly and v_fma_mix_f32 rounds once, like the fused
+    multiply-add above): the interval still contains the FP64 one of the single-precision box."""
+    rng = np.random.default_rng(77)
+    entered = 0
+    for lo, hi, o, inv, scale in cases(rng, 20000):
+        lo16 = np.array([F(half_outwards(v, False)) for v in lo], dtype=F)
+        hi16 = np.array([F(half_outwards(v, True)) for v in hi], dtype=F)
+        assert np.all(lo16 <= lo) and np.all(hi16 >= hi)
+        tn64, tf64 = slab_f64(lo.astype(np.float64), hi.astype(np.float64), o, inv)
+        # |plane| <= scene_scale is what the widening assumes: the half-precision planes of a tree stay
+        # inside the scene box rounded outwards, 2^-10 beyond it at most
+        scale16 = max(scale, float(max(np.abs(lo16).max(), np.abs(hi16).max())))
+        tn16, tf16 = slab_f32(lo16, hi16, o, inv, scale16)
+        ok64 = tn64 <= tf64 and tf64 >= 0.0
+        ok16 = tn16 <= tf16 and tf16 >= F(0.0)
+        assert ok16 or not ok64, (lo, hi, o, inv)
+        entered += ok64
+    assert entered > 2500
