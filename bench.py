@@ -261,7 +261,10 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # BENCH_DIST=1 (under torch.distributed.run with one process) takes the N > 1 code path -- process
+    # group, gathers, reductions -- with a single rank: RCCL's calls rehearsed on a one-GPU box
+    collective = world > 1 or os.environ.get("BENCH_DIST") == "1"
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -270,7 +273,8 @@ def main():
     device.init(dev_index)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
     counters = load_counters()
-    ctx = dict(args=args, rank=rank, world=world, dev=dev, comm_dev=comm_dev, backend=backend, counters=counters)
+    ctx = dict(args=args, rank=rank, world=world, dev=dev, comm_dev=comm_dev, backend=backend, counters=counters,
+               collective=collective)
 
     out = None
     if args.only in ("all", "main"):
@@ -301,7 +305,7 @@ def main():
         out["configs"] = other_configs(ctx, ("c1", "c3", "c5"))
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -311,6 +315,7 @@ def main_workload(ctx):
     import torch.distributed as dist
     from raytracer_amd import abi, device, scenes
     args, rank, world, dev, comm_dev, backend = (ctx[k] for k in ("args", "rank", "world", "dev", "comm_dev", "backend"))
+    collective = ctx["collective"]
     W, H = args.width, args.height
     mesh = None if args.mesh == "procedural" else args.mesh
     scene, _ = scenes.mesh_scene(mesh=mesh)
@@ -343,7 +348,7 @@ def main_workload(ctx):
     fbs = [fb] + [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(F - 1)]
     shown = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2 * F)]
     gathered = [[torch.zeros((H, W, 3), dtype=torch.uint8, device=comm_dev) for _ in range(world)]
-                if (world > 1 and rank == 0) else None for _ in range(2 * F)]
+                if (collective and rank == 0) else None for _ in range(2 * F)]
     pending = [None] * (2 * F)
 
     def step_fn(step, flags):
@@ -356,7 +361,7 @@ def main_workload(ctx):
             # the frame replaces what the buffer held (the reference clears it per frame)
             st = handles[h].render_device(rd_for(step, flags | abi.FLAG_OVERWRITE), fbs[h].data_ptr())
             handles[h].present_device(fbs[h].data_ptr(), W, H, shown[k].data_ptr(), passes=1, tonemap=abi.TONEMAP_NONE, flip=True)
-            if world > 1:
+            if collective:
                 src = shown[k] if backend == "nccl" else shown[k].cpu()
                 pending[k] = dist.gather(src, gathered[k], dst=0, async_op=True)
         return st
@@ -387,7 +392,7 @@ def main_workload(ctx):
         h.wait()
 
     def sync():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -470,7 +475,7 @@ def main_workload(ctx):
             }
 
     tt = torch.tensor([elapsed, float(rays)] + spread, dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if collective:
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -548,6 +553,7 @@ def frame_16spp(ctx, kind):
     from raytracer_amd import abi, device, scenes
     from raytracer_amd import dist as rdist
     args, rank, world, dev, comm_dev = (ctx[k] for k in ("args", "rank", "world", "dev", "comm_dev"))
+    collective = ctx["collective"]
     W, H = args.width, args.height
     frames = max(1, args.frames16)
     mesh = None if args.mesh == "procedural" else args.mesh
@@ -586,7 +592,7 @@ def frame_16spp(ctx, kind):
                                        comm_device=None if comm_dev == dev else comm_dev)
 
     def sync():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -611,7 +617,7 @@ def frame_16spp(ctx, kind):
     sync()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt, float(acc["rays"])], dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if collective:
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -683,6 +689,7 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight, partition):
     from raytracer_amd import abi
     from raytracer_amd import dist as rdist
     args, rank, world, dev, comm_dev, backend = (ctx[k] for k in ("args", "rank", "world", "dev", "comm_dev", "backend"))
+    collective = ctx["collective"]
     W, H = args.width, args.height
     F = max(1, in_flight)
     by_rows = partition == "rows"
@@ -699,10 +706,10 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight, partition):
         h.set_async(True)
     packed = [torch.zeros((most, W, 3), dtype=torch.float32, device=dev) for _ in range(F)]
     shown = [torch.zeros((most, W, 3), dtype=torch.uint8, device=dev) for _ in range(F)]
-    gathered = [torch.zeros((world, most, W, 3), dtype=torch.uint8, device=comm_dev) if (world > 1 and rank == 0) else None
+    gathered = [torch.zeros((world, most, W, 3), dtype=torch.uint8, device=comm_dev) if (collective and rank == 0) else None
                 for _ in range(F)]
     frame_buf = [torch.zeros((per_rank * world * 8, W, 3), dtype=torch.uint8, device=comm_dev)
-                 if (by_rows and world > 1 and rank == 0) else None for _ in range(F)]
+                 if (by_rows and collective and rank == 0) else None for _ in range(F)]
     pending = [None] * F
     tonemap = abi.TONEMAP_CBRT if kind == "path" else abi.TONEMAP_NONE
 
@@ -735,7 +742,7 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight, partition):
                 handles[k].render_device(rd, packed[k].data_ptr())
                 handles[k].present_device(packed[k].data_ptr(), W, rows, shown[k].data_ptr(), passes=1, tonemap=tonemap,
                                           flip=not by_rows)
-            if world > 1:
+            if collective:
                 src = shown[k] if backend == "nccl" else shown[k].cpu()
                 frame_of[k] = j
                 pending[k] = dist.gather(src, list(gathered[k].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
@@ -753,7 +760,7 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight, partition):
                 pending[k] = None
 
     def sync():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -771,7 +778,7 @@ def pipelined_frames(ctx, kind, ds, rd_for, frames, in_flight, partition):
     sync()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt, float(rays)], dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if collective:
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)

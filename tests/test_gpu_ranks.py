@@ -55,3 +55,25 @@ def test_two_ranks_on_one_gpu_print_one_line_with_both_scalings(gpu):
         assert out["strong_scaling"][kind]["pipelined_ms_per_frame"] == f["pipelined"]["ms_per_frame"]
     # the rays of the frames the two ranks rendered, summed: more than one rank's share of the steps
     assert out["rays_per_frame"] > 320 * 184
+
+
+@pytest.mark.gpu
+def test_one_rank_through_rccl(gpu):
+    """The N > 1 code path of bench.py -- process group with a device id, asynchronous gathers of the
+    presented frames on the frames' streams, barriers, reductions -- with RCCL itself as the transport and
+    a single rank (BENCH_DIST=1), which is all a one-GPU box can offer RCCL."""
+    env = dict(os.environ, BENCH_DIST="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    env.pop("BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+           "--repeats", "0", "--frames16", "4", "--width", "320", "--height", "184", "--mesh", "teapot", "--texture-size", "256",
+           "--no-cpu-baseline", "--no-serial-leg", "--no-configs", "--sequence-leg", "--checksums"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    for kind in ("whitted_area_light", "path_ggx"):
+        f = out["frame_16spp"][kind]
+        assert f["ms_per_frame"] > 0 and f["pipelined"]["ms_per_frame"] > 0 and f["sequence"]["ms_per_frame"] > 0
