@@ -1182,6 +1182,17 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
     p.d.pixel_multisample_n = n;
     p.n = n;
     p.band_stride = 1;
+    // what every ray of the frame would otherwise work out for itself (RenderParams)
+    p.div_band = make_fast_div(8u * rd->tile_w);
+    p.div_nn = make_fast_div(n * n);
+    p.div_n = make_fast_div(n);
+    p.div_group = make_fast_div(rd->tile_row_group ? rd->tile_row_group : 1u);
+    p.div_stride = make_fast_div(rd->tile_row_stride ? rd->tile_row_stride : 1u);
+    {
+        const double cx = 1.0 / ((double)rd->width - 1.0), cy = 1.0 / ((double)rd->height - 1.0);
+        p.sub_step_x = cx / (double)(n + 1);
+        p.sub_step_y = cy / (double)(n + 1);
+    }
     const uint64_t padded_pixels = (uint64_t)rd->tile_w * rd->tile_h;     // every index is a pixel
     if (padded_pixels * n * n > 0xffffffffull) return fail(RTX_ERR_LIMIT, "more than 2^32 samples per pass in one tile");
     uint32_t nn = n * n;

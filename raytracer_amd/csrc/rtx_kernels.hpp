@@ -55,8 +55,42 @@ struct GatherQueue {
 
 struct Counters { unsigned long long* c; };     // 8 global work counters, or null
 
+// Division of a 32-bit unsigned number by a divisor every thread of a launch shares (Granlund and
+// Montgomery, "Division by invariant integers using multiplication", 1994, figure 4.1): the host works
+// out a multiplier and two shifts once, the device spends a multiply-high, two adds and two shifts
+// where a division by a register takes some twenty instructions.  Exact for every n and every d >= 1.
+struct FastDiv {
+    uint32_t mul, shift1, shift2, d;
+};
+inline FastDiv make_fast_div(uint32_t d)
+{
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 0;
+    while (l < 32 && (1ull << l) < d) ++l;          // ceil(log2 d)
+    f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.shift1 = l < 1 ? l : 1;
+    f.shift2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& f)
+{
+    const uint32_t t = __umulhi(f.mul, n);
+    return (t + ((n - t) >> f.shift1)) >> f.shift2;
+}
+
 struct RenderParams {
     rtx_render_desc d;
+    // derived from d by the host (fill_derived): divisors of the pixel and sub-sample indices, and the
+    // camera's sub-sample offsets offx = sx * (cx / (n + 1)) with cx = 1 / (width - 1) (Raytracer.cpp:
+    // 676-700) -- the two divisions are the same for every ray of the frame and are done once, in the
+    // same FP64 arithmetic
+    FastDiv div_band;           // by 8 * tile_w
+    FastDiv div_nn;             // by n * n
+    FastDiv div_n;              // by n
+    FastDiv div_group;          // by tile_row_group (1 when rows are not grouped)
+    FastDiv div_stride;         // by tile_row_stride
+    double sub_step_x, sub_step_y;
     uint32_t chunk_t0;          // first pixel index (in the order of pixel_of) of this chunk
     uint32_t chunk_pixels;      // pixels in this chunk
     uint32_t pass;
@@ -1072,41 +1106,50 @@ RTX_DEV void add_static_efficiency(Counters, const Work<false>&) {}
 RTX_DEV void pixel_of(const RenderParams& p, uint32_t t, uint32_t& x, uint32_t& y)
 {
     const uint32_t W = p.d.tile_w, H = p.d.tile_h;
-    const uint32_t own_band = t / (8u * W);            // among the chunk's own bands (all full but possibly the tile's last)
+    const uint32_t own_band = fast_div(t, p.div_band);  // among the chunk's own bands (all full but possibly the tile's last)
     uint32_t r = t - own_band * 8u * W;
     const uint32_t band = own_band * p.band_stride + p.band_first;
     uint32_t hb = min(8u, H - 8u * band);
-    uint32_t bx = r / (8u * hb);
+    // (blocks are 8 x 8 except in the tile's last band and last column: shifts, not divisions, for the rest)
+    uint32_t bx = hb == 8u ? r >> 6 : r / (8u * hb);
     uint32_t r2 = r - bx * 8u * hb;
     uint32_t wb = min(8u, W - 8u * bx);
-    uint32_t ly = r2 / wb, lx = r2 - ly * wb;
+    uint32_t ly = wb == 8u ? r2 >> 3 : r2 / wb, lx = r2 - ly * wb;
     x = p.d.tile_x0 + bx * 8u + lx;
     const uint32_t row = band * 8u + ly;            // row of the tile
-    y = p.d.tile_y0 + (p.d.tile_row_group ? (row / p.d.tile_row_group) * p.d.tile_row_stride + row % p.d.tile_row_group : row);
+    uint32_t gy = row;
+    if (p.d.tile_row_group) {
+        const uint32_t group = fast_div(row, p.div_group);
+        gy = group * p.d.tile_row_stride + (row - group * p.d.tile_row_group);
+    }
+    y = p.d.tile_y0 + gy;
 }
 // the tile row of frame row y (the inverse of the mapping above)
 RTX_DEV uint32_t tile_row_of(const RenderParams& p, uint32_t y)
 {
     const uint32_t dy = y - p.d.tile_y0;
-    return p.d.tile_row_group ? (dy / p.d.tile_row_stride) * p.d.tile_row_group + dy % p.d.tile_row_stride : dy;
+    if (!p.d.tile_row_group) return dy;
+    const uint32_t group = fast_div(dy, p.div_stride);
+    return group * p.d.tile_row_group + (dy - group * p.d.tile_row_stride);
 }
 
 // The camera ray of sample slot `slot` of the chunk (Raytracer.cpp:676-700).
 RTX_DEV Ray camera_ray(const RenderParams& p, uint32_t slot)
 {
     uint32_t nn = p.n * p.n;
-    uint32_t t = p.chunk_t0 + slot / nn, sub = slot % nn;
+    const uint32_t pixel = fast_div(slot, p.div_nn), sub = slot - pixel * nn;
+    uint32_t t = p.chunk_t0 + pixel;
     uint32_t x, y;
     pixel_of(p, t, x, y);
-    uint32_t sx = sub / p.n + 1, sy = sub % p.n + 1;
+    const uint32_t sub_x = fast_div(sub, p.div_n);
+    uint32_t sx = sub_x + 1, sy = sub - sub_x * p.n + 1;
     const rtx_camera& c = p.d.camera;
     double nx = ((double)x / (double)p.d.width) - 0.5;
     double ny = ((double)y / (double)p.d.height) - 0.5;
     d3 eye = ld3(c.eye);
     d3 on_screen = (((ld3(c.right) * nx) + (ld3(c.up) * ny)) + eye) + (ld3(c.forward) * c.focal);
-    double cx = 1.0 / ((double)p.d.width - 1.0), cy = 1.0 / ((double)p.d.height - 1.0);
-    double offx = (double)sx * (cx / (double)(p.n + 1));
-    double offy = (double)sy * (cy / (double)(p.n + 1));
+    double offx = (double)sx * p.sub_step_x;
+    double offy = (double)sy * p.sub_step_y;
     d3 v = normalize3((on_screen + mk(offx, offy, 0.0)) - eye);
     return make_ray(eye, v);
 }
@@ -1564,11 +1607,21 @@ RTX_DEV void sample_add(const RenderParams& p, double* sample, uint32_t slot, d3
 // drawBuffer[x + y*frameX] += colorAcum / double(n*n) (Raytracer.cpp:710) for pixel k of the
 // chunk: the quotient is rounded to float and added in FP32 (or stored: 0.0f + it is what
 // adding to a cleared buffer gives).
+// v / (double)count.  When the count is a power of two its reciprocal is exact and the product
+// is the same correctly rounded value as the quotient, for a multiplication in place of an FP64 division
+// sequence per component (sample counts are 1, 4, 16, 64 in the reference's configurations); any other
+// count is divided by.
+RTX_DEV d3 div_by_count(d3 v, uint32_t count)
+{
+    if ((count & (count - 1u)) == 0u && count != 0u) return v * __hiloint2double((int)((1023u - (uint32_t)__ffs((int)count) + 1u) << 20), 0);
+    return v / (double)count;
+}
+
 RTX_DEV void resolve_pixel(const RenderParams& p, uint32_t k, d3 acum, float* accum)
 {
     uint32_t x, y;
     pixel_of(p, p.chunk_t0 + k, x, y);
-    d3 px = acum / (double)(p.n * p.n);
+    d3 px = div_by_count(acum, p.n * p.n);
     size_t at = 3 * ((size_t)(x - p.d.tile_x0) + (size_t)tile_row_of(p, y) * p.d.tile_w);
     if (p.overwrite) {
         accum[at + 0] = 0.0f + (float)px.x;
@@ -1616,7 +1669,8 @@ RTX_DEV void sample_term(const RenderParams& p, double* sample, uint32_t slot, d
 RTX_DEV Rng ray_rng(const RenderParams& p, const RayQueue& q, uint32_t i, uint32_t slot)
 {
     uint32_t nn = p.n * p.n;
-    uint32_t t = p.chunk_t0 + slot / nn, sub = slot % nn;
+    const uint32_t pixel = fast_div(slot, p.div_nn), sub = slot - pixel * nn;
+    uint32_t t = p.chunk_t0 + pixel;
     uint32_t x, y;
     pixel_of(p, t, x, y);
     Rng r;
@@ -1762,7 +1816,9 @@ k_tile_scatter(DScene s, RayQueue q, uint32_t n, const uint32_t* __restrict__ n_
 // the per-level factors and the terminal value is added once to its sample.
 // `perm` (optional) lists the queue entries in the order they are to be shaded: thread j
 // shades ray perm[j].
-__global__ void __launch_bounds__(kBlock)
+// (five waves per SIMD: left to itself the register allocation wavers between 96 and 100, i.e. between
+// five waves and four, with changes elsewhere in the file; four cost the pathTrace frame 1.5 %)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5)))
 k_shade_path(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32_t* __restrict__ n_device,
              const uint32_t* __restrict__ perm, RayQueue next, uint32_t* next_count, double* sample)
 {
@@ -1977,7 +2033,7 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
                         direct = direct + lighting(inv_dir, ld, h.normal, att, mcolor, mns, ld3(l.color));
                     }
                 }
-                direct = direct / (double)samples;          // inside the light loop (:498)
+                direct = div_by_count(direct, samples);      // inside the light loop (:498)
                 if (GATHER && p.gather_samples) {           // GLOBAL_LIGHTING (:499-524)
                     for (uint32_t gm = 0; gm < p.gather_samples; ++gm, g += stride) {
                         int32_t gp = p.gather_traced ? gq.hit_prim[g] : -1;
@@ -1997,7 +2053,7 @@ k_shade_whitted_b(DScene s, RenderParams p, RayQueue q, uint32_t n, const uint32
                             global = global + (clear * 0.04);
                         }
                     }
-                    global = global / (double)p.d.global_samples;      // :523
+                    global = div_by_count(global, p.d.global_samples);  // :523
                 }
             }
             local = direct + global;
