@@ -1173,6 +1173,8 @@ static int render_impl(rtx_scene* sc, const rtx_render_desc* rd, float* accum, r
     }
     uint32_t n = rd->pixel_multisample_n ? rd->pixel_multisample_n : 1;
     if (n > 64) return fail(RTX_ERR_LIMIT, "pixel_multisample_n > 64");
+    // (a band of 8 rows is indexed with 32 bits)
+    if (rd->tile_w > (1u << 28)) return fail(RTX_ERR_LIMIT, "tile_w %u: tiles are at most 2^28 pixels wide", rd->tile_w);
     const bool whitted = rd->integrator == RTX_INTEGRATOR_WHITTED;
     const bool count_work = (rd->flags & RTX_FLAG_COUNTERS) != 0;
 
